@@ -1,0 +1,189 @@
+#!/usr/bin/env python3
+"""Benchmark of the hot path: device-resident int64 column decode (FOR + zig-zag + bit-pack).
+
+Workload (N=1): one synthetic 2^28-row int64 column per GPU, narrow value range
+(v = 1.7e12 + sm(seed, i) mod 4000, bit width 12 after the frame of reference), encoded on the
+device by this library, then decoded K times.  A step = one decode of the whole column:
+402,653,197 encoded bytes read, 2 GiB of int64 written.  With --gpus N every rank holds its own
+column (rows [rank*2^28, (rank+1)*2^28) of the same generator): weak scaling, no collectives on
+the data path.
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak
+SEED = 0x5EED0002
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--rows-log2", type=int, default=28, help="rows per GPU = 2^this (default 28: the named config)")
+    ap.add_argument("--cpu-seconds", type=float, default=10.0, help="CPU-baseline budget; 0 disables it")
+    ap.add_argument("--no-encode-bench", action="store_true")
+    return ap.parse_args()
+
+
+def cpu_baseline(n_sample: int, budget_s: float):
+    """The C restatement of the reference codec (oracle/, kind 'port'), one core, decoding the
+    first n_sample rows of the same column.  Test infrastructure used as a reported baseline."""
+    import numpy as np
+
+    from oracle import zbra_oracle_c as oc
+    v = oc.gen_narrow(SEED, 0, n_sample)
+    enc = np.frombuffer(oc.compress_int_array(v), dtype=np.uint8).copy()
+    out = np.empty(n_sample, dtype=np.int64)
+    oc.decompress_int_array_into(enc, n_sample, out)  # warm
+    assert np.array_equal(out, v)
+    reps, t0 = 0, time.perf_counter()
+    while True:
+        oc.decompress_int_array_into(enc, n_sample, out)
+        reps += 1
+        el = time.perf_counter() - t0
+        if el >= budget_s or reps >= 200:
+            break
+    dec_gbps = 8.0 * n_sample * reps / el / 1e9
+    # encode leg (sort-based median dominates): one timed call on a smaller slice
+    m = min(n_sample, 1 << 22)
+    buf = np.empty(13 + 8 * m, dtype=np.uint8)
+    t1 = time.perf_counter()
+    oc.compress_int_array_into(v[:m], buf)
+    enc_gbps = 8.0 * m / (time.perf_counter() - t1) / 1e9
+    return {"value": round(dec_gbps, 4), "unit": "GB/s", "cores": 1, "kind": "port",
+            "sample": f"first 2^{n_sample.bit_length() - 1} rows of the same column, {reps} reps, "
+                      f"C restatement of zbra-core compression.rs (gcc -O3), decode only",
+            "encode_GBps": round(enc_gbps, 4)}
+
+
+def main():
+    args = parse_args()
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: zbra_amd has no CPU path")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group(backend="nccl", device_id=dev)
+
+    from zbra_amd import device, workloads
+
+    n = 1 << args.rows_log2
+    # -- setup (untimed): generate on device, encode on device ------------------------------
+    values = workloads.narrow_column(SEED, rank * n, n, dev)
+    cap = device.encode_bound(n)
+    enc_buf = torch.empty(cap, dtype=torch.uint8, device=dev)
+    res = device.new_results(1, dev)
+    device.encode_dev(values, enc_buf, res)
+    r = device.read_results(res)[0]
+    assert r.status == 0 and r.width == 12, (r.status, r.width)
+    enc_len = int(r.out_count)
+    assert enc_len == 13 + (n * 12 + 7) // 8
+    encoded = enc_buf[:enc_len].clone()  # exact-size copy: E at its own allocation
+    del enc_buf
+    out = torch.empty(n, dtype=torch.int64, device=dev)
+    dres = device.new_results(1, dev)
+
+    def step():
+        device.decode_dev(encoded, n, out, dres)
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    assert torch.equal(out, values), "decode(encode(v)) != v"
+    assert device.read_results(dres)[0].out_count == n
+
+    # -- timed region ------------------------------------------------------------------------
+    ev0 = torch.cuda.Event(enable_timing=True)  # events on the stream the kernels run on
+    ev1 = torch.cuda.Event(enable_timing=True)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    ev0.record()
+    for _ in range(args.steps):
+        step()
+    ev1.record()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    kernel_ms = ev0.elapsed_time(ev1) / args.steps  # per decode launch (plan + tile kernel)
+
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # -- encode timing (secondary; same config names encode + decode) -------------------------
+    encode = None
+    if not args.no_encode_bench:
+        enc_buf = torch.empty(cap, dtype=torch.uint8, device=dev)
+        for _ in range(2):
+            device.encode_dev(values, enc_buf, res)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        reps = 10
+        e0.record()
+        for _ in range(reps):
+            device.encode_dev(values, enc_buf, res)
+        e1.record()
+        torch.cuda.synchronize()
+        enc_ms = e0.elapsed_time(e1) / reps
+        assert torch.equal(enc_buf[:enc_len], encoded)
+        encode = {"ms": round(enc_ms, 4), "GBps_in": round(8.0 * n / enc_ms / 1e6, 2),
+                  "algorithmic_GBps": round((16.0 * n + enc_len) / enc_ms / 1e6, 2)}
+        del enc_buf
+
+    if rank == 0:
+        decoded_bytes = 8.0 * n * world * args.steps
+        value = decoded_bytes / elapsed / 1e9
+        algo_bytes = enc_len + 8.0 * n  # per launch: encoded bytes read + int64 written
+        achieved = algo_bytes / (kernel_ms * 1e-3) / 1e9
+        line = {
+            "metric": "device-resident int64 column decode GB/s (FOR+zigzag+bitpack)",
+            "value": round(value, 2),
+            "unit": "GB/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "int64",
+            "data": "synthetic",
+            "config": {"workload": f"single 2^{args.rows_log2}-row int64 column per GPU, v=1.7e12+sm(0x5EED0002,i) mod 4000, "
+                                   "bit width 12, decode of device-resident bytes",
+                       "rows_per_gpu": n, "bit_width": 12, "encoded_bytes": enc_len, "partitioning": f"columns x{world}, no collectives"},
+            "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None,
+                         "kernel": "decode_tiles_kernel", "kernel_ms": round(kernel_ms, 4),
+                         "algorithmic_bytes_per_launch": int(algo_bytes)},
+        }
+        if encode is not None:
+            line["encode"] = encode
+        if world == 1 and args.cpu_seconds > 0:
+            line["cpu_baseline"] = cpu_baseline(min(n, 1 << 25), args.cpu_seconds)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,159 @@
+/*
+ * zbra_hip.h — C ABI of libzbra_hip.so: Zbra's integer column codec
+ * (frame-of-reference by median, zig-zag, fixed-width LSB-first bit-packing
+ * with a raw 8-byte fallback at width >= 32) as HIP kernels for gfx950.
+ *
+ * The reference has no FFI seam for this path: the seam is the eight public
+ * functions of zbra-core/src/compression.rs and the six private framing
+ * helpers of zbra-core/src/binary.rs:639-674 that call them.  Every entry
+ * point below names the reference function it replaces.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; caller allocates every output;
+ *   - return value: 0 = ZBRA_OK, otherwise a zbra_status; values >= 100 carry
+ *     a hipError_t (status - 100);
+ *   - the reference's "empty" conventions are results, not errors:
+ *       compress_int_array([])            -> 0 bytes          compression.rs:272-274
+ *       decompress_int_array(b"", count)  -> 0 values         compression.rs:296-298
+ *       bp64_unpack(b"", count)           -> 0 values         compression.rs:182-184
+ *   - functions without a _dev suffix take HOST pointers, run on the current
+ *     HIP device and return after the result is in host memory;
+ *   - functions with a _dev suffix take DEVICE pointers, enqueue work on the
+ *     given stream (a hipStream_t passed as void*, NULL = the null stream)
+ *     and return without synchronising; results that are only known on the
+ *     device (status, lengths) land in a zbra_dev_result in device memory;
+ *   - all entry points use the calling thread's current HIP device; calls on
+ *     different streams or devices may run concurrently from different
+ *     threads.  There is no CPU fallback: without a usable device every
+ *     compute entry point fails with ZBRA_ERR_NO_DEVICE.
+ */
+#ifndef ZBRA_HIP_H
+#define ZBRA_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum zbra_status {
+    ZBRA_OK = 0,
+    /* BinaryError::DecompressionError("Invalid compressed data length")     compression.rs:300-304 */
+    ZBRA_ERR_SHORT_HEADER = 1,
+    /* BinaryError::DecompressionError("Insufficient data for packed array") compression.rs:312-316 */
+    ZBRA_ERR_SHORT_PACKED = 2,
+    /* Packed payload shorter than ceil(count*width/8) bytes.  The reference underflows a u32
+     * there (compression.rs:229: panic in debug, garbage in release); this library reports it. */
+    ZBRA_ERR_TRUNCATED = 3,
+    ZBRA_ERR_CAPACITY = 4,    /* caller's output buffer is too small */
+    ZBRA_ERR_INVALID_ARG = 5, /* NULL pointer with a non-zero size, count above 2^32-1, ... */
+    ZBRA_ERR_NO_DEVICE = 6,   /* no HIP device / HIP runtime unusable */
+    ZBRA_ERR_HIP_BASE = 100   /* status - 100 = hipError_t */
+} zbra_status;
+
+/* What kind of values an int array carries (binary.rs:639-674). */
+typedef enum zbra_elem_kind {
+    ZBRA_ELEM_I64 = 0, /* Vec<i64> / Vec<usize> / f64 bit patterns  binary.rs:639-664, 299-300 */
+    ZBRA_ELEM_U32 = 1  /* Vec<u32> enum tags: widened `as i64` on write, narrowed `as u32` on read
+                          binary.rs:666-674 */
+} zbra_elem_kind;
+
+/* Result words a _dev call leaves in DEVICE memory (32 bytes). */
+typedef struct zbra_dev_result {
+    uint32_t status;    /* zbra_status of this array */
+    uint32_t width;     /* bit width byte of the encoded array (0 if none) */
+    uint64_t out_count; /* decode: values produced; encode: bytes produced */
+    int64_t midpoint;   /* frame-of-reference midpoint */
+    uint64_t packed_len;/* value of the u32 length field (1 + payload bytes) */
+} zbra_dev_result;
+
+/* One encoded int array of a batch: where its `E` bytes are (the `clen` bytes that follow the
+ * `u32 count | u32 clen` frame of binary.rs:639-645), and where its values go. */
+typedef struct zbra_array_desc {
+    const uint8_t *data; /* first byte of E (the midpoint) */
+    uint64_t len;        /* clen */
+    uint64_t count;      /* count from the frame */
+    void *out;           /* count elements of `kind` */
+    uint32_t kind;       /* zbra_elem_kind */
+    uint32_t reserved;
+} zbra_array_desc;
+
+/* One int array of an encode batch: values in, E out. */
+typedef struct zbra_encode_desc {
+    const void *values; /* n elements of `kind` */
+    uint64_t n;
+    uint8_t *out;       /* receives E */
+    uint64_t cap;       /* bytes available at `out`; zbra_hip_encode_bound(n) always suffices */
+    uint32_t kind;      /* zbra_elem_kind */
+    uint32_t reserved;
+} zbra_encode_desc;
+
+/* ---- library / device ------------------------------------------------------------------- */
+
+const char *zbra_hip_version(void);
+const char *zbra_hip_strerror(int status);
+int zbra_hip_device_count(int *count);
+int zbra_hip_set_device(int device);
+/* Creates the per-device context (workspaces) ahead of the first call. Optional. */
+int zbra_hip_init(void);
+
+/* 13 + 8*n for n > 0, else 0: capacity that compress_int_array's result never exceeds. */
+size_t zbra_hip_encode_bound(size_t n);
+
+/* ---- full pipeline, host pointers --------------------------------------------------------- */
+
+/* compress_int_array(values: &[i64]) -> Vec<u8>                      compression.rs:271-292 */
+int zbra_hip_encode_i64(const int64_t *values, size_t n, uint8_t *out, size_t cap, size_t *out_len);
+/* write_u32_array_compressed's widen + compress_int_array            binary.rs:666-669 */
+int zbra_hip_encode_u32(const uint32_t *values, size_t n, uint8_t *out, size_t cap, size_t *out_len);
+/* decompress_int_array(data: &[u8], count) -> Vec<i64>               compression.rs:295-330
+ * `out` holds `count` elements; *out_count = length of the Vec the reference returns. */
+int zbra_hip_decode_i64(const uint8_t *data, size_t len, size_t count, int64_t *out, size_t *out_count);
+/* read_u32_array_compressed's decompress + narrow `as u32`            binary.rs:671-674 */
+int zbra_hip_decode_u32(const uint8_t *data, size_t len, size_t count, uint32_t *out, size_t *out_count);
+
+/* ---- stage functions, host pointers ------------------------------------------------------- */
+
+/* frame_of_reference_encode(values) -> (midpoint, deltas)            compression.rs:52-74 */
+int zbra_hip_frame_of_reference_encode(const int64_t *values, size_t n, int64_t *midpoint, int64_t *deltas);
+/* frame_of_reference_decode(midpoint, deltas) -> values              compression.rs:77-82 */
+int zbra_hip_frame_of_reference_decode(int64_t midpoint, const int64_t *deltas, size_t n, int64_t *out);
+/* zig_zag_encode(values) -> Vec<u64>                                 compression.rs:88-98 */
+int zbra_hip_zig_zag_encode(const int64_t *values, size_t n, uint64_t *out);
+/* zig_zag_decode(values) -> Vec<i64>                                 compression.rs:101-111 */
+int zbra_hip_zig_zag_decode(const uint64_t *values, size_t n, int64_t *out);
+/* bp64_pack(values) -> Vec<u8>; cap >= 1 + 8*n always suffices       compression.rs:117-178 */
+int zbra_hip_bp64_pack(const uint64_t *values, size_t n, uint8_t *out, size_t cap, size_t *out_len);
+/* bp64_unpack(packed, count) -> Vec<u64>                             compression.rs:181-233 */
+int zbra_hip_bp64_unpack(const uint8_t *packed, size_t packed_len, size_t count, uint64_t *out, size_t *out_count);
+
+/* ---- device-resident, stream-ordered (the measured path) --------------------------------- */
+
+/* decompress_int_array on bytes already in HBM.  d_data: `len` bytes of E; d_out: `count`
+ * elements of `kind`; d_result (may be NULL): status, width, out_count, midpoint.
+ * `len` and `count` are host values because the frame that carries them (binary.rs:648-650) is
+ * read by the host; everything inside E is parsed on the device.     compression.rs:295-330 */
+int zbra_hip_decode_dev(const uint8_t *d_data, size_t len, size_t count, void *d_out, uint32_t kind,
+                        zbra_dev_result *d_result, void *stream);
+
+/* The same for `nd` independent arrays in one submission (all arrays of a Block, or of many
+ * Blocks: binary.rs:359-441 decodes them one after another).  `descs` is a HOST array whose
+ * data/out members are DEVICE pointers; d_results (may be NULL) receives nd entries. */
+int zbra_hip_decode_batch_dev(const zbra_array_desc *descs, size_t nd, zbra_dev_result *d_results, void *stream);
+
+/* compress_int_array on values already in HBM.  d_out must hold zbra_hip_encode_bound(n) bytes;
+ * the encoded length is only known on the device: d_result->out_count (d_result must not be
+ * NULL).                                                             compression.rs:271-292 */
+int zbra_hip_encode_dev(const void *d_values, size_t n, uint32_t kind, uint8_t *d_out, size_t cap,
+                        zbra_dev_result *d_result, void *stream);
+
+/* The same for `nd` independent arrays in one submission (Column::write_to encodes the arrays of
+ * a Block one after another, binary.rs:275-356).  `descs` is a HOST array of DEVICE pointers;
+ * d_results receives nd entries (status, width, midpoint, out_count = bytes of E). */
+int zbra_hip_encode_batch_dev(const zbra_encode_desc *descs, size_t nd, zbra_dev_result *d_results, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ZBRA_HIP_H */

@@ -1,0 +1,75 @@
+"""CPU checks of the C-ABI boundary: the library loads, exports exactly what include/zbra_hip.h
+declares, and refuses to compute without a device (no CPU fallback).  No compute calls."""
+import ctypes as C
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+
+
+def _declared():
+    text = open(os.path.join(ROOT, "include", "zbra_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(zbra_hip_\w+)\s*\(", text)))
+
+
+def test_header_symbols_exported_and_bound():
+    from zbra_amd import _lib
+    declared = _declared()
+    assert len(declared) >= 20
+    assert sorted(_lib.SIGNATURES) == declared
+    for name in declared:
+        assert hasattr(_lib.lib, name), name
+    out = subprocess.check_output(["nm", "-D", "--defined-only", _lib.LIB_PATH], text=True)
+    exported = set(re.findall(r"\bT (zbra_hip_\w+)", out))
+    assert exported == set(declared)
+
+
+def test_header_compiles_as_c():
+    src = '#include "zbra_hip.h"\nint main(void){zbra_array_desc d; zbra_dev_result r; (void)d; (void)r; return sizeof(zbra_dev_result)==32 && sizeof(zbra_array_desc)==40 && sizeof(zbra_encode_desc)==40 ? 0 : 1;}\n'
+    exe = "/tmp/zbra_hdr_check"
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-pedantic", "-I", os.path.join(ROOT, "include"), "-x", "c", "-",
+                    "-o", exe], input=src, text=True, check=True)
+    assert subprocess.run([exe]).returncode == 0
+
+
+def test_struct_layouts_match_ctypes():
+    from zbra_amd import _lib
+    assert C.sizeof(_lib.DevResult) == 32 and C.sizeof(_lib.ArrayDesc) == 40 and C.sizeof(_lib.EncodeDesc) == 40
+
+
+def test_pure_host_answers():
+    from zbra_amd._lib import lib, strerror
+    assert lib.zbra_hip_encode_bound(0) == 0 and lib.zbra_hip_encode_bound(10) == 93
+    assert strerror(1) == "Invalid compressed data length"          # compression.rs:302
+    assert strerror(2) == "Insufficient data for packed array"      # compression.rs:314
+    assert b"gfx950" in lib.zbra_hip_version()
+
+
+def test_fails_loudly_without_device():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    from zbra_amd import compression as zc
+    with pytest.raises(zc.DeviceError):
+        zc.compress_int_array(np.arange(10, dtype=np.int64))
+    with pytest.raises(zc.DeviceError):
+        zc.decompress_int_array(bytes.fromhex("030000000000000003000000030b44"), 5)
+    # results that need no device are still exact: empty in, empty out
+    assert zc.compress_int_array(np.zeros(0, dtype=np.int64)) == b""
+    assert zc.decompress_int_array(b"", 3).size == 0
+    with pytest.raises(zc.DecompressionError):
+        zc.decompress_int_array(b"\0" * 5, 1)
+
+
+def test_product_does_not_import_oracle():
+    pkg = os.path.join(ROOT, "zbra_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".hpp", ".h", ".cpp")):
+                text = open(os.path.join(dirpath, f)).read()
+                assert "oracle" not in text.lower(), os.path.join(dirpath, f)

@@ -1,0 +1,94 @@
+"""Loads libzbra_hip.so (the HIP kernels + C ABI) and declares its entry points.
+
+There is no fallback: if the shared library is missing, importing this module raises.
+"""
+import ctypes as C
+import os
+import sys
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libzbra_hip.so")
+
+
+class DevResult(C.Structure):
+    """zbra_dev_result of include/zbra_hip.h."""
+    _fields_ = [("status", C.c_uint32), ("width", C.c_uint32), ("out_count", C.c_uint64),
+                ("midpoint", C.c_int64), ("packed_len", C.c_uint64)]
+
+
+class ArrayDesc(C.Structure):
+    """zbra_array_desc of include/zbra_hip.h."""
+    _fields_ = [("data", C.c_void_p), ("len", C.c_uint64), ("count", C.c_uint64), ("out", C.c_void_p),
+                ("kind", C.c_uint32), ("reserved", C.c_uint32)]
+
+
+class EncodeDesc(C.Structure):
+    """zbra_encode_desc of include/zbra_hip.h."""
+    _fields_ = [("values", C.c_void_p), ("n", C.c_uint64), ("out", C.c_void_p), ("cap", C.c_uint64),
+                ("kind", C.c_uint32), ("reserved", C.c_uint32)]
+
+
+_p, _sz = C.c_void_p, C.c_size_t
+_psz = C.POINTER(C.c_size_t)
+
+# name -> (restype, argtypes); one line per declaration of include/zbra_hip.h
+SIGNATURES = {
+    "zbra_hip_version": (C.c_char_p, []),
+    "zbra_hip_strerror": (C.c_char_p, [C.c_int]),
+    "zbra_hip_device_count": (C.c_int, [C.POINTER(C.c_int)]),
+    "zbra_hip_set_device": (C.c_int, [C.c_int]),
+    "zbra_hip_init": (C.c_int, []),
+    "zbra_hip_encode_bound": (_sz, [_sz]),
+    "zbra_hip_encode_i64": (C.c_int, [_p, _sz, _p, _sz, _psz]),
+    "zbra_hip_encode_u32": (C.c_int, [_p, _sz, _p, _sz, _psz]),
+    "zbra_hip_decode_i64": (C.c_int, [_p, _sz, _sz, _p, _psz]),
+    "zbra_hip_decode_u32": (C.c_int, [_p, _sz, _sz, _p, _psz]),
+    "zbra_hip_frame_of_reference_encode": (C.c_int, [_p, _sz, C.POINTER(C.c_int64), _p]),
+    "zbra_hip_frame_of_reference_decode": (C.c_int, [C.c_int64, _p, _sz, _p]),
+    "zbra_hip_zig_zag_encode": (C.c_int, [_p, _sz, _p]),
+    "zbra_hip_zig_zag_decode": (C.c_int, [_p, _sz, _p]),
+    "zbra_hip_bp64_pack": (C.c_int, [_p, _sz, _p, _sz, _psz]),
+    "zbra_hip_bp64_unpack": (C.c_int, [_p, _sz, _sz, _p, _psz]),
+    "zbra_hip_decode_dev": (C.c_int, [_p, _sz, _sz, _p, C.c_uint32, _p, _p]),
+    "zbra_hip_decode_batch_dev": (C.c_int, [C.POINTER(ArrayDesc), _sz, _p, _p]),
+    "zbra_hip_encode_dev": (C.c_int, [_p, _sz, C.c_uint32, _p, _sz, _p, _p]),
+    "zbra_hip_encode_batch_dev": (C.c_int, [C.POINTER(EncodeDesc), _sz, _p, _p]),
+}
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: build it with `make -C zbra_amd/csrc` (or __graft_entry__.build()). "
+            "zbra_amd has no CPU fallback.")
+    # When torch is (or will be) in the process, its bundled HIP runtime must be the one both use,
+    # or device pointers made by torch are foreign to this library: load torch's first.
+    if "torch" not in sys.modules and os.environ.get("ZBRA_HIP_NO_TORCH") != "1":
+        try:
+            import torch  # noqa: F401
+        except Exception:
+            pass
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the library does not export a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    return lib
+
+
+lib = _load()
+
+OK = 0
+ERR_SHORT_HEADER = 1
+ERR_SHORT_PACKED = 2
+ERR_TRUNCATED = 3
+ERR_CAPACITY = 4
+ERR_INVALID_ARG = 5
+ERR_NO_DEVICE = 6
+ERR_HIP_BASE = 100
+ELEM_I64 = 0
+ELEM_U32 = 1
+
+
+def strerror(status: int) -> str:
+    return lib.zbra_hip_strerror(status).decode()

@@ -1,0 +1,451 @@
+// C ABI of libzbra_hip.so (declared in include/zbra_hip.h) over the kernels of
+// zbra_decode.hpp / zbra_encode.hpp / zbra_stages.hpp.  gfx950 only; there is no CPU path.
+#include <hip/hip_runtime.h>
+
+#include <cstring>
+#include <map>
+#include <mutex>
+#include <vector>
+
+#include "zbra_context.hpp"
+#include "zbra_decode.hpp"
+#include "zbra_encode.hpp"
+#include "zbra_stages.hpp"
+
+namespace zbra {
+
+static std::mutex g_ctx_mu;
+static std::map<int, DeviceCtx *> g_ctx;
+
+int current_ctx(DeviceCtx **out) {
+    int dev = -1;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        return ZBRA_ERR_NO_DEVICE;
+    }
+    std::lock_guard<std::mutex> g(g_ctx_mu);
+    auto it = g_ctx.find(dev);
+    if (it != g_ctx.end()) { *out = it->second; return ZBRA_OK; }
+    DeviceCtx *c = new DeviceCtx();
+    c->device = dev;
+    e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) { delete c; return hip_status(e); }
+    g_ctx[dev] = c;
+    *out = c;
+    return ZBRA_OK;
+}
+
+static inline uint64_t tiles_of(uint64_t count) { return (count + TILE - 1) / TILE; }
+static inline unsigned grid_for(uint64_t ntiles, unsigned cap) { return (unsigned)(ntiles < cap ? (ntiles ? ntiles : 1) : cap); }
+static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+constexpr unsigned DECODE_GRID_CAP = 256 * 8;  // 8 workgroups of 4 waves per CU
+constexpr unsigned STREAM_GRID_CAP = 256 * 8;
+constexpr unsigned HIST_GRID_CAP = 256 * 4;    // 16 KiB of LDS histogram per workgroup
+
+// ---- decode, device-resident ---------------------------------------------------------------
+
+static int decode_batch_dev(DeviceCtx *ctx, const zbra_array_desc *descs, size_t nd, zbra_dev_result *d_results,
+                            hipStream_t stream) {
+    if (nd == 0) return ZBRA_OK;
+    if (!descs || nd > 0xFFFFFFFFull) return ZBRA_ERR_INVALID_ARG;
+    for (size_t i = 0; i < nd; i++) {
+        const zbra_array_desc &d = descs[i];
+        if (d.count > MAX_COUNT || d.kind > ZBRA_ELEM_U32) return ZBRA_ERR_INVALID_ARG;
+        if ((d.len && !d.data) || (d.count && d.len && !d.out)) return ZBRA_ERR_INVALID_ARG;
+    }
+    if (nd == 1) {
+        const uint64_t ntiles = tiles_of(descs[0].count);
+        Slot *s;
+        ZBRA_TRY(ctx->acquire(256, &s));
+        DecodePlan *plan = (DecodePlan *)s->dev;
+        uint64_t *tile_start = (uint64_t *)((char *)s->dev + 64);
+        hipLaunchKernelGGL(plan_decode_one_kernel, dim3(1), dim3(64), 0, stream, descs[0], ntiles, plan, tile_start,
+                           d_results);
+        if (ntiles)
+            hipLaunchKernelGGL(decode_tiles_kernel, dim3(grid_for(ntiles, DECODE_GRID_CAP)), dim3(THREADS), 0, stream,
+                               plan, tile_start, 1u, ntiles);
+        int st = hip_status(hipGetLastError());
+        int st2 = ctx->release(s, stream);
+        return st != ZBRA_OK ? st : st2;
+    }
+    const size_t off_ts = align_up(nd * sizeof(zbra_array_desc), 64);
+    const size_t off_plan = align_up(off_ts + (nd + 1) * sizeof(uint64_t), 64);
+    const size_t total = off_plan + nd * sizeof(DecodePlan);
+    Slot *s;
+    ZBRA_TRY(ctx->acquire(total, &s));
+    std::memcpy(s->host, descs, nd * sizeof(zbra_array_desc));
+    uint64_t *h_ts = (uint64_t *)((char *)s->host + off_ts);
+    uint64_t run = 0;
+    for (size_t i = 0; i < nd; i++) { h_ts[i] = run; run += tiles_of(descs[i].count); }
+    h_ts[nd] = run;
+    const uint64_t ntiles = run;
+    int st = hip_status(hipMemcpyAsync(s->dev, s->host, off_ts + (nd + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, stream));
+    if (st == ZBRA_OK) {
+        const zbra_array_desc *d_descs = (const zbra_array_desc *)s->dev;
+        const uint64_t *d_ts = (const uint64_t *)((char *)s->dev + off_ts);
+        DecodePlan *d_plans = (DecodePlan *)((char *)s->dev + off_plan);
+        hipLaunchKernelGGL(plan_decode_batch_kernel, dim3((unsigned)((nd + 255) / 256)), dim3(256), 0, stream, d_descs,
+                           (uint32_t)nd, d_plans, d_results);
+        if (ntiles)
+            hipLaunchKernelGGL(decode_tiles_kernel, dim3(grid_for(ntiles, DECODE_GRID_CAP)), dim3(THREADS), 0, stream,
+                               d_plans, d_ts, (uint32_t)nd, ntiles);
+        st = hip_status(hipGetLastError());
+    }
+    int st2 = ctx->release(s, stream);
+    return st != ZBRA_OK ? st : st2;
+}
+
+// ---- encode, device-resident ---------------------------------------------------------------
+
+struct EncodeItem {
+    const void *values;
+    uint64_t n;
+    uint32_t kind;
+    uint8_t *out;
+    uint64_t cap;
+};
+
+enum EncodeMode { ENCODE_FULL, ENCODE_MEDIAN_ONLY };
+
+static int encode_batch_dev(DeviceCtx *ctx, const EncodeItem *items, size_t nd, zbra_dev_result *d_results,
+                            hipStream_t stream, EncodeMode mode = ENCODE_FULL) {
+    if (nd == 0) return ZBRA_OK;
+    if (!items || nd > 0xFFFFFFFFull) return ZBRA_ERR_INVALID_ARG;
+    for (size_t i = 0; i < nd; i++) {
+        if (items[i].n > MAX_COUNT || items[i].kind > KIND_U64_PLAIN) return ZBRA_ERR_INVALID_ARG;
+        if (items[i].n && (!items[i].values || (mode == ENCODE_FULL && !items[i].out))) return ZBRA_ERR_INVALID_ARG;
+    }
+    const size_t off_ts = align_up(nd * sizeof(EncodeJob), 64);
+    const size_t off_hist = align_up(off_ts + (nd + 1) * sizeof(uint64_t), 256);
+    const size_t total = off_hist + nd * BINS * sizeof(uint32_t);
+    Slot *s;
+    ZBRA_TRY(ctx->acquire(total, &s));
+    EncodeJob *h_jobs = (EncodeJob *)s->host;
+    uint64_t *h_ts = (uint64_t *)((char *)s->host + off_ts);
+    uint64_t run = 0;
+    for (size_t i = 0; i < nd; i++) {
+        EncodeJob j;
+        std::memset(&j, 0, sizeof(j));
+        j.values = items[i].values; j.out = items[i].out; j.n = items[i].n; j.cap = items[i].cap; j.kind = items[i].kind;
+        j.min_b = ~0ull; j.max_b = 0; j.next_above = ~0ull;
+        h_jobs[i] = j;
+        h_ts[i] = run;
+        run += tiles_of(items[i].n);
+    }
+    h_ts[nd] = run;
+    const uint64_t ntiles = run;
+    EncodeJob *d_jobs = (EncodeJob *)s->dev;
+    const uint64_t *d_ts = (const uint64_t *)((char *)s->dev + off_ts);
+    uint32_t *d_hist = (uint32_t *)((char *)s->dev + off_hist);
+    int st = hip_status(hipMemcpyAsync(s->dev, s->host, off_ts + (nd + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, stream));
+    if (st == ZBRA_OK) st = hip_status(hipMemsetAsync(d_hist, 0, nd * BINS * sizeof(uint32_t), stream));
+    if (st == ZBRA_OK) {
+        const unsigned gs = grid_for(ntiles, STREAM_GRID_CAP);
+        const unsigned gh = grid_for(ntiles, HIST_GRID_CAP);
+        const unsigned ga = (unsigned)((nd + 255) / 256);
+        if (ntiles) hipLaunchKernelGGL(enc_minmax_kernel, dim3(gs), dim3(THREADS), 0, stream, d_jobs, d_ts, (uint32_t)nd, ntiles);
+        hipLaunchKernelGGL(enc_setup_kernel, dim3(ga), dim3(256), 0, stream, d_jobs, (uint32_t)nd);
+        if (ntiles) {
+            for (uint32_t pass = 0; pass < (uint32_t)MAX_PASSES; pass++) {
+                hipLaunchKernelGGL(enc_hist_kernel, dim3(gh), dim3(THREADS), 0, stream, d_jobs, d_ts, (uint32_t)nd, ntiles,
+                                   d_hist, pass);
+                hipLaunchKernelGGL(enc_select_kernel, dim3((unsigned)nd), dim3(THREADS), 0, stream, d_jobs, d_hist, pass);
+            }
+            if (mode == ENCODE_FULL)
+                hipLaunchKernelGGL(enc_or_kernel, dim3(gs), dim3(THREADS), 0, stream, d_jobs, d_ts, (uint32_t)nd, ntiles);
+        }
+        if (mode == ENCODE_FULL) {
+            hipLaunchKernelGGL(enc_finalize_kernel, dim3(ga), dim3(256), 0, stream, d_jobs, (uint32_t)nd, d_results);
+            if (ntiles)
+                hipLaunchKernelGGL(enc_pack_kernel, dim3(gs), dim3(THREADS), 0, stream, d_jobs, d_ts, (uint32_t)nd, ntiles);
+        } else {
+            hipLaunchKernelGGL(enc_report_median_kernel, dim3(ga), dim3(256), 0, stream, d_jobs, (uint32_t)nd, d_results);
+        }
+        st = hip_status(hipGetLastError());
+    }
+    int st2 = ctx->release(s, stream);
+    return st != ZBRA_OK ? st : st2;
+}
+
+// ---- host-pointer helpers ------------------------------------------------------------------
+
+// Host-side reading of the header, for the synchronous calls: same rules as plan_one.
+static int host_check_decode(const uint8_t *data, size_t len, size_t count, size_t *out_count) {
+    *out_count = 0;
+    if (len == 0) return ZBRA_OK;
+    if (len < 12) return ZBRA_ERR_SHORT_HEADER;
+    uint32_t pl;
+    std::memcpy(&pl, data + 8, 4);  // x86-64 host: little-endian
+    if (len < 12 + (size_t)pl) return ZBRA_ERR_SHORT_PACKED;
+    if (pl == 0 || count == 0) return ZBRA_OK;
+    const uint32_t w = data[12];
+    if (w >= 1 && w < 32 && (uint64_t)(pl - 1) < ((uint64_t)count * w + 7) / 8) return ZBRA_ERR_TRUNCATED;
+    *out_count = count;
+    return ZBRA_OK;
+}
+
+static int decode_host(const uint8_t *data, size_t len, size_t count, void *out, uint32_t kind, size_t *out_count) {
+    if (!out_count || (len && !data)) return ZBRA_ERR_INVALID_ARG;
+    if (count > MAX_COUNT) return ZBRA_ERR_INVALID_ARG;
+    size_t produced = 0;
+    ZBRA_TRY(host_check_decode(data, len, count, &produced));
+    *out_count = produced;
+    if (produced == 0) return ZBRA_OK;
+    if (!out) return ZBRA_ERR_INVALID_ARG;
+    DeviceCtx *ctx;
+    ZBRA_TRY(current_ctx(&ctx));
+    std::lock_guard<std::mutex> g(ctx->host_mu);
+    const size_t esz = kind == ZBRA_ELEM_I64 ? 8 : 4;
+    const size_t used = 12 + (size_t)(*(const uint32_t *)(data + 8));  // bytes after 12 + packed_len are ignored
+    ZBRA_TRY(DeviceCtx::grow_dev(ctx->dev_in, used + 16));
+    ZBRA_TRY(DeviceCtx::grow_dev(ctx->dev_out, count * esz));
+    ZBRA_HIP_TRY(hipMemcpyAsync(ctx->dev_in.ptr, data, used, hipMemcpyHostToDevice, ctx->stream));
+    zbra_array_desc d;
+    d.data = (const uint8_t *)ctx->dev_in.ptr; d.len = used; d.count = count; d.out = ctx->dev_out.ptr; d.kind = kind; d.reserved = 0;
+    ZBRA_TRY(decode_batch_dev(ctx, &d, 1, nullptr, ctx->stream));
+    ZBRA_HIP_TRY(hipMemcpyAsync(out, ctx->dev_out.ptr, count * esz, hipMemcpyDeviceToHost, ctx->stream));
+    ZBRA_HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return ZBRA_OK;
+}
+
+static int encode_host(const void *values, size_t n, uint32_t kind, uint8_t *out, size_t cap, size_t *out_len) {
+    if (!out_len || (n && !values)) return ZBRA_ERR_INVALID_ARG;
+    *out_len = 0;
+    if (n == 0) return ZBRA_OK;  // compression.rs:272-274
+    if (n > MAX_COUNT) return ZBRA_ERR_INVALID_ARG;
+    DeviceCtx *ctx;
+    ZBRA_TRY(current_ctx(&ctx));
+    std::lock_guard<std::mutex> g(ctx->host_mu);
+    const size_t esz = kind == ZBRA_ELEM_I64 ? 8 : 4;
+    const size_t bound = zbra_hip_encode_bound(n);
+    ZBRA_TRY(DeviceCtx::grow_dev(ctx->dev_in, n * esz));
+    ZBRA_TRY(DeviceCtx::grow_dev(ctx->dev_out, bound + 16));
+    ZBRA_TRY(DeviceCtx::grow_dev(ctx->dev_tmp, sizeof(zbra_dev_result)));
+    ZBRA_HIP_TRY(hipMemcpyAsync(ctx->dev_in.ptr, values, n * esz, hipMemcpyHostToDevice, ctx->stream));
+    EncodeItem it{ctx->dev_in.ptr, n, kind, (uint8_t *)ctx->dev_out.ptr, bound};
+    ZBRA_TRY(encode_batch_dev(ctx, &it, 1, (zbra_dev_result *)ctx->dev_tmp.ptr, ctx->stream));
+    zbra_dev_result r;
+    ZBRA_HIP_TRY(hipMemcpyAsync(&r, ctx->dev_tmp.ptr, sizeof(r), hipMemcpyDeviceToHost, ctx->stream));
+    ZBRA_HIP_TRY(hipStreamSynchronize(ctx->stream));
+    if (r.status != ZBRA_OK) return (int)r.status;
+    if (r.out_count > cap || !out) return ZBRA_ERR_CAPACITY;
+    ZBRA_HIP_TRY(hipMemcpy(out, ctx->dev_out.ptr, r.out_count, hipMemcpyDeviceToHost));
+    *out_len = r.out_count;
+    return ZBRA_OK;
+}
+
+// Runs an elementwise stage kernel over host buffers.
+template <typename Launch>
+static int stage_host(const void *in, size_t in_bytes, void *out, size_t out_bytes, Launch &&launch) {
+    if ((in_bytes && !in) || (out_bytes && !out)) return ZBRA_ERR_INVALID_ARG;
+    if (in_bytes == 0) return ZBRA_OK;
+    DeviceCtx *ctx;
+    ZBRA_TRY(current_ctx(&ctx));
+    std::lock_guard<std::mutex> g(ctx->host_mu);
+    ZBRA_TRY(DeviceCtx::grow_dev(ctx->dev_in, in_bytes));
+    ZBRA_TRY(DeviceCtx::grow_dev(ctx->dev_out, out_bytes));
+    ZBRA_HIP_TRY(hipMemcpyAsync(ctx->dev_in.ptr, in, in_bytes, hipMemcpyHostToDevice, ctx->stream));
+    launch(ctx->dev_in.ptr, ctx->dev_out.ptr, ctx->stream);
+    ZBRA_HIP_TRY(hipGetLastError());
+    ZBRA_HIP_TRY(hipMemcpyAsync(out, ctx->dev_out.ptr, out_bytes, hipMemcpyDeviceToHost, ctx->stream));
+    ZBRA_HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return ZBRA_OK;
+}
+
+}  // namespace zbra
+
+using namespace zbra;
+
+extern "C" {
+
+const char *zbra_hip_version(void) { return "zbra-hip 0.1 (gfx950)"; }
+
+const char *zbra_hip_strerror(int status) {
+    switch (status) {
+        case ZBRA_OK: return "ok";
+        case ZBRA_ERR_SHORT_HEADER: return "Invalid compressed data length";       // compression.rs:302
+        case ZBRA_ERR_SHORT_PACKED: return "Insufficient data for packed array";   // compression.rs:314
+        case ZBRA_ERR_TRUNCATED: return "Packed payload shorter than count * width bits";
+        case ZBRA_ERR_CAPACITY: return "Output buffer too small";
+        case ZBRA_ERR_INVALID_ARG: return "Invalid argument";
+        case ZBRA_ERR_NO_DEVICE: return "No usable HIP device";
+        default:
+            if (status >= ZBRA_ERR_HIP_BASE) return hipGetErrorString((hipError_t)(status - ZBRA_ERR_HIP_BASE));
+            return "unknown status";
+    }
+}
+
+int zbra_hip_device_count(int *count) {
+    if (!count) return ZBRA_ERR_INVALID_ARG;
+    *count = 0;
+    hipError_t e = hipGetDeviceCount(count);
+    if (e != hipSuccess) { (void)hipGetLastError(); *count = 0; return ZBRA_ERR_NO_DEVICE; }
+    return ZBRA_OK;
+}
+
+int zbra_hip_set_device(int device) { return hip_status(hipSetDevice(device)); }
+
+int zbra_hip_init(void) {
+    DeviceCtx *ctx;
+    return current_ctx(&ctx);
+}
+
+size_t zbra_hip_encode_bound(size_t n) { return n == 0 ? 0 : 13 + 8 * n; }
+
+int zbra_hip_encode_i64(const int64_t *values, size_t n, uint8_t *out, size_t cap, size_t *out_len) {
+    return encode_host(values, n, ZBRA_ELEM_I64, out, cap, out_len);
+}
+int zbra_hip_encode_u32(const uint32_t *values, size_t n, uint8_t *out, size_t cap, size_t *out_len) {
+    return encode_host(values, n, ZBRA_ELEM_U32, out, cap, out_len);
+}
+int zbra_hip_decode_i64(const uint8_t *data, size_t len, size_t count, int64_t *out, size_t *out_count) {
+    return decode_host(data, len, count, out, ZBRA_ELEM_I64, out_count);
+}
+int zbra_hip_decode_u32(const uint8_t *data, size_t len, size_t count, uint32_t *out, size_t *out_count) {
+    return decode_host(data, len, count, out, ZBRA_ELEM_U32, out_count);
+}
+
+int zbra_hip_frame_of_reference_encode(const int64_t *values, size_t n, int64_t *midpoint, int64_t *deltas) {
+    if (!midpoint || (n && (!values || !deltas))) return ZBRA_ERR_INVALID_ARG;
+    *midpoint = 0;
+    if (n == 0) return ZBRA_OK;  // compression.rs:53-55
+    if (n > MAX_COUNT) return ZBRA_ERR_INVALID_ARG;
+    DeviceCtx *ctx;
+    ZBRA_TRY(current_ctx(&ctx));
+    std::lock_guard<std::mutex> g(ctx->host_mu);
+    ZBRA_TRY(DeviceCtx::grow_dev(ctx->dev_in, n * 8));
+    ZBRA_TRY(DeviceCtx::grow_dev(ctx->dev_out, n * 8));
+    ZBRA_TRY(DeviceCtx::grow_dev(ctx->dev_tmp, sizeof(zbra_dev_result)));
+    ZBRA_HIP_TRY(hipMemcpyAsync(ctx->dev_in.ptr, values, n * 8, hipMemcpyHostToDevice, ctx->stream));
+    EncodeItem it{ctx->dev_in.ptr, n, ZBRA_ELEM_I64, nullptr, 0};
+    ZBRA_TRY(encode_batch_dev(ctx, &it, 1, (zbra_dev_result *)ctx->dev_tmp.ptr, ctx->stream, ENCODE_MEDIAN_ONLY));
+    const unsigned grid = grid_for((n + THREADS * 2 - 1) / (THREADS * 2), STREAM_GRID_CAP);
+    hipLaunchKernelGGL(for_sub_kernel, dim3(grid), dim3(THREADS), 0, ctx->stream, (const int64_t *)ctx->dev_in.ptr,
+                       (uint64_t)n, (const zbra_dev_result *)ctx->dev_tmp.ptr, (int64_t *)ctx->dev_out.ptr);
+    ZBRA_HIP_TRY(hipGetLastError());
+    zbra_dev_result r;
+    ZBRA_HIP_TRY(hipMemcpyAsync(&r, ctx->dev_tmp.ptr, sizeof(r), hipMemcpyDeviceToHost, ctx->stream));
+    ZBRA_HIP_TRY(hipMemcpyAsync(deltas, ctx->dev_out.ptr, n * 8, hipMemcpyDeviceToHost, ctx->stream));
+    ZBRA_HIP_TRY(hipStreamSynchronize(ctx->stream));
+    *midpoint = r.midpoint;
+    return ZBRA_OK;
+}
+
+int zbra_hip_frame_of_reference_decode(int64_t midpoint, const int64_t *deltas, size_t n, int64_t *out) {
+    return stage_host(deltas, n * 8, out, n * 8, [&](void *din, void *dout, hipStream_t st) {
+        const unsigned grid = grid_for((n + THREADS * 2 - 1) / (THREADS * 2), STREAM_GRID_CAP);
+        hipLaunchKernelGGL(for_add_kernel, dim3(grid), dim3(THREADS), 0, st, (const int64_t *)din, (uint64_t)n, midpoint,
+                           (int64_t *)dout);
+    });
+}
+
+int zbra_hip_zig_zag_encode(const int64_t *values, size_t n, uint64_t *out) {
+    return stage_host(values, n * 8, out, n * 8, [&](void *din, void *dout, hipStream_t st) {
+        const unsigned grid = grid_for((n + THREADS * 2 - 1) / (THREADS * 2), STREAM_GRID_CAP);
+        hipLaunchKernelGGL(zigzag_encode_kernel, dim3(grid), dim3(THREADS), 0, st, (const int64_t *)din, (uint64_t)n,
+                           (uint64_t *)dout);
+    });
+}
+
+int zbra_hip_zig_zag_decode(const uint64_t *values, size_t n, int64_t *out) {
+    return stage_host(values, n * 8, out, n * 8, [&](void *din, void *dout, hipStream_t st) {
+        const unsigned grid = grid_for((n + THREADS * 2 - 1) / (THREADS * 2), STREAM_GRID_CAP);
+        hipLaunchKernelGGL(zigzag_decode_kernel, dim3(grid), dim3(THREADS), 0, st, (const uint64_t *)din, (uint64_t)n,
+                           (int64_t *)dout);
+    });
+}
+
+int zbra_hip_bp64_pack(const uint64_t *values, size_t n, uint8_t *out, size_t cap, size_t *out_len) {
+    if (!out_len || (n && !values)) return ZBRA_ERR_INVALID_ARG;
+    *out_len = 0;
+    if (n == 0) return ZBRA_OK;  // compression.rs:118-120
+    if (n > MAX_COUNT) return ZBRA_ERR_INVALID_ARG;
+    DeviceCtx *ctx;
+    ZBRA_TRY(current_ctx(&ctx));
+    std::lock_guard<std::mutex> g(ctx->host_mu);
+    const size_t bound = 1 + 8 * n;
+    ZBRA_TRY(DeviceCtx::grow_dev(ctx->dev_in, n * 8));
+    ZBRA_TRY(DeviceCtx::grow_dev(ctx->dev_out, 12 + bound + 32));
+    ZBRA_TRY(DeviceCtx::grow_dev(ctx->dev_tmp, sizeof(zbra_dev_result)));
+    ZBRA_HIP_TRY(hipMemcpyAsync(ctx->dev_in.ptr, values, n * 8, hipMemcpyHostToDevice, ctx->stream));
+    // The stream is built by the encode pipeline with values taken as they are; its E layout puts
+    // the width byte at +12, so `packed` is E without the 12 header bytes.
+    EncodeItem it{ctx->dev_in.ptr, n, KIND_U64_PLAIN, (uint8_t *)ctx->dev_out.ptr, 12 + bound};
+    ZBRA_TRY(encode_batch_dev(ctx, &it, 1, (zbra_dev_result *)ctx->dev_tmp.ptr, ctx->stream));
+    zbra_dev_result r;
+    ZBRA_HIP_TRY(hipMemcpyAsync(&r, ctx->dev_tmp.ptr, sizeof(r), hipMemcpyDeviceToHost, ctx->stream));
+    ZBRA_HIP_TRY(hipStreamSynchronize(ctx->stream));
+    if (r.status != ZBRA_OK) return (int)r.status;
+    const size_t len = (size_t)r.packed_len;
+    if (len > cap || !out) return ZBRA_ERR_CAPACITY;
+    ZBRA_HIP_TRY(hipMemcpy(out, (uint8_t *)ctx->dev_out.ptr + 12, len, hipMemcpyDeviceToHost));
+    *out_len = len;
+    return ZBRA_OK;
+}
+
+int zbra_hip_bp64_unpack(const uint8_t *packed, size_t packed_len, size_t count, uint64_t *out, size_t *out_count) {
+    if (!out_count || (packed_len && !packed)) return ZBRA_ERR_INVALID_ARG;
+    *out_count = 0;
+    if (packed_len == 0) return ZBRA_OK;  // compression.rs:182-184
+    if (count > MAX_COUNT) return ZBRA_ERR_INVALID_ARG;
+    if (count == 0) return ZBRA_OK;
+    if (!out) return ZBRA_ERR_INVALID_ARG;
+    const uint32_t w = packed[0];
+    if (w >= 1 && w < 32 && (uint64_t)(packed_len - 1) < ((uint64_t)count * w + 7) / 8) return ZBRA_ERR_TRUNCATED;
+    DeviceCtx *ctx;
+    ZBRA_TRY(current_ctx(&ctx));
+    std::lock_guard<std::mutex> g(ctx->host_mu);
+    ZBRA_TRY(DeviceCtx::grow_dev(ctx->dev_in, packed_len + 32));
+    ZBRA_TRY(DeviceCtx::grow_dev(ctx->dev_out, count * 8));
+    ZBRA_HIP_TRY(hipMemcpyAsync(ctx->dev_in.ptr, packed, packed_len, hipMemcpyHostToDevice, ctx->stream));
+    ZBRA_TRY(DeviceCtx::grow_dev(ctx->dev_tmp, 256));
+    const uint64_t ntiles = tiles_of(count);
+    DecodePlan *plan = (DecodePlan *)ctx->dev_tmp.ptr;
+    uint64_t *tile_start = (uint64_t *)((char *)ctx->dev_tmp.ptr + 64);
+    hipLaunchKernelGGL(plan_unpack_kernel, dim3(1), dim3(64), 0, ctx->stream, (const uint8_t *)ctx->dev_in.ptr,
+                       (uint64_t)packed_len, (uint64_t)count, ctx->dev_out.ptr, ntiles, plan, tile_start);
+    hipLaunchKernelGGL(decode_tiles_kernel, dim3(grid_for(ntiles, DECODE_GRID_CAP)), dim3(THREADS), 0, ctx->stream, plan,
+                       tile_start, 1u, ntiles);
+    ZBRA_HIP_TRY(hipGetLastError());
+    ZBRA_HIP_TRY(hipMemcpyAsync(out, ctx->dev_out.ptr, count * 8, hipMemcpyDeviceToHost, ctx->stream));
+    ZBRA_HIP_TRY(hipStreamSynchronize(ctx->stream));
+    *out_count = count;
+    return ZBRA_OK;
+}
+
+int zbra_hip_decode_dev(const uint8_t *d_data, size_t len, size_t count, void *d_out, uint32_t kind,
+                        zbra_dev_result *d_result, void *stream) {
+    DeviceCtx *ctx;
+    ZBRA_TRY(current_ctx(&ctx));
+    zbra_array_desc d;
+    d.data = d_data; d.len = len; d.count = count; d.out = d_out; d.kind = kind; d.reserved = 0;
+    return decode_batch_dev(ctx, &d, 1, d_result, (hipStream_t)stream);
+}
+
+int zbra_hip_decode_batch_dev(const zbra_array_desc *descs, size_t nd, zbra_dev_result *d_results, void *stream) {
+    DeviceCtx *ctx;
+    ZBRA_TRY(current_ctx(&ctx));
+    return decode_batch_dev(ctx, descs, nd, d_results, (hipStream_t)stream);
+}
+
+int zbra_hip_encode_dev(const void *d_values, size_t n, uint32_t kind, uint8_t *d_out, size_t cap,
+                        zbra_dev_result *d_result, void *stream) {
+    if (!d_result) return ZBRA_ERR_INVALID_ARG;
+    DeviceCtx *ctx;
+    ZBRA_TRY(current_ctx(&ctx));
+    EncodeItem it{d_values, n, kind, d_out, cap};
+    return encode_batch_dev(ctx, &it, 1, d_result, (hipStream_t)stream);
+}
+
+int zbra_hip_encode_batch_dev(const zbra_encode_desc *descs, size_t nd, zbra_dev_result *d_results, void *stream) {
+    DeviceCtx *ctx;
+    ZBRA_TRY(current_ctx(&ctx));
+    if (nd && !descs) return ZBRA_ERR_INVALID_ARG;
+    std::vector<EncodeItem> items(nd);
+    for (size_t i = 0; i < nd; i++) items[i] = EncodeItem{descs[i].values, descs[i].n, descs[i].kind, descs[i].out, descs[i].cap};
+    return encode_batch_dev(ctx, items.data(), nd, d_results, (hipStream_t)stream);
+}
+
+}  // extern "C"

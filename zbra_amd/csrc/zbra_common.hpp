@@ -1,0 +1,80 @@
+// Shared device-side definitions of libzbra_hip (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "zbra_hip.h"
+
+namespace zbra {
+
+// Values of one tile (one workgroup iteration).  A multiple of 64 so that a tile of any width w
+// starts on a byte boundary of the packed stream: TILE*w bits = 256*w bytes.
+constexpr int TILE = 2048;
+constexpr int THREADS = 256;
+constexpr uint32_t MAX_COUNT = 0xFFFFFFFFu;  // `values.len() as u32`, binary.rs:640
+
+// Internal element kind of the stage functions bp64_pack / bp64_unpack: u64 values that are
+// packed / unpacked as they are (no frame of reference, no zig-zag).
+constexpr uint32_t KIND_U64_PLAIN = 2;
+
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef uint64_t u64x2 __attribute__((ext_vector_type(2)));
+
+// Pointers that reach a kernel through a descriptor in memory are generic to the compiler, which
+// then emits flat_* instructions; every buffer of this library is global memory, so say so.
+#define ZBRA_GLOBAL __attribute__((address_space(1)))
+template <typename T>
+__device__ __forceinline__ const ZBRA_GLOBAL T *gptr(uintptr_t p) { return (const ZBRA_GLOBAL T *)p; }
+template <typename T>
+__device__ __forceinline__ const ZBRA_GLOBAL T *gptr(const void *p) { return (const ZBRA_GLOBAL T *)p; }
+template <typename T>
+__device__ __forceinline__ ZBRA_GLOBAL T *gptr_mut(uintptr_t p) { return (ZBRA_GLOBAL T *)p; }
+template <typename T>
+__device__ __forceinline__ ZBRA_GLOBAL T *gptr_mut(void *p) { return (ZBRA_GLOBAL T *)p; }
+
+// Decode plan of one array, produced on the device from the array's own header.
+struct DecodePlan {
+    const uint8_t *payload;  // first byte after the width byte (E + 13)
+    void *out;
+    uint64_t count;          // values to write; 0 = nothing to do (empty, or rejected)
+    int64_t midpoint;
+    uint64_t avail;          // payload bytes present: packed_len - 1
+    uint32_t width;          // width byte as stored, 0..255
+    uint32_t kind;           // zbra_elem_kind
+};
+
+__device__ __forceinline__ uint64_t load_le64_bytes(const uint8_t *p) {
+    uint64_t v = 0;
+#pragma unroll
+    for (int b = 0; b < 8; b++) v |= (uint64_t)p[b] << (8 * b);
+    return v;
+}
+__device__ __forceinline__ uint32_t load_le32_bytes(const uint8_t *p) {
+    uint32_t v = 0;
+#pragma unroll
+    for (int b = 0; b < 4; b++) v |= (uint32_t)p[b] << (8 * b);
+    return v;
+}
+
+// zig_zag_decode, compression.rs:101-111
+__device__ __forceinline__ int64_t zigzag_decode64(uint64_t n) {
+    return (int64_t)((n >> 1) ^ (0 - (n & 1)));
+}
+// zig_zag_encode, compression.rs:88-98
+__device__ __forceinline__ uint64_t zigzag_encode64(int64_t n) {
+    return ((uint64_t)n << 1) ^ (uint64_t)(n >> 63);
+}
+
+// First array whose tile range contains tile t: largest a with tile_start[a] <= t.
+// tile_start has nd + 1 entries; every lane of the workgroup computes the same answer.
+__device__ __forceinline__ uint32_t find_array(const uint64_t *__restrict__ tile_start, uint32_t nd, uint64_t t) {
+    uint32_t lo = 0, hi = nd;  // invariant: tile_start[lo] <= t < tile_start[hi]
+    while (hi - lo > 1) {
+        uint32_t mid = (lo + hi) >> 1;
+        if (tile_start[mid] <= t) lo = mid; else hi = mid;
+    }
+    return lo;
+}
+
+}  // namespace zbra

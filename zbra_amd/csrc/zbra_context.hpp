@@ -1,0 +1,113 @@
+// Per-device host-side state of libzbra_hip: workspace slots that a stream-ordered call borrows
+// for its descriptor tables, and grow-only device/pinned buffers behind the host-pointer calls.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <mutex>
+#include <vector>
+
+#include "zbra_hip.h"
+
+namespace zbra {
+
+inline int hip_status(hipError_t e) { return e == hipSuccess ? ZBRA_OK : ZBRA_ERR_HIP_BASE + (int)e; }
+
+#define ZBRA_HIP_TRY(expr)                                    \
+    do {                                                      \
+        hipError_t _e = (expr);                               \
+        if (_e != hipSuccess) return ZBRA_ERR_HIP_BASE + (int)_e; \
+    } while (0)
+
+#define ZBRA_TRY(expr)                 \
+    do {                               \
+        int _s = (expr);               \
+        if (_s != ZBRA_OK) return _s;  \
+    } while (0)
+
+// A pair of equally sized buffers (pinned host + device) lent to ONE enqueued call.  The host
+// side may be rewritten only after everything the previous borrower enqueued has run, which the
+// slot's event says.
+struct Slot {
+    void *host = nullptr;
+    void *dev = nullptr;
+    size_t cap = 0;
+    hipEvent_t done = nullptr;
+    bool busy = false;  // between acquire() and release()
+};
+
+// Grow-only buffer.
+struct Arena {
+    void *ptr = nullptr;
+    size_t cap = 0;
+};
+
+struct DeviceCtx {
+    int device = -1;
+    std::mutex mu;              // guards slots
+    std::vector<Slot *> slots;  // pointers stay valid while the vector grows
+    std::mutex host_mu;         // serialises host-pointer calls: they share the arenas and the stream
+    hipStream_t stream = nullptr;
+    Arena dev_in, dev_out, dev_tmp;
+    Arena pin_in, pin_out;
+
+    int acquire(size_t bytes, Slot **out) {
+        std::lock_guard<std::mutex> g(mu);
+        for (Slot *s : slots) {
+            if (s->busy || s->cap < bytes) continue;
+            if (hipEventQuery(s->done) != hipSuccess) {
+                (void)hipGetLastError();  // hipErrorNotReady is not a failure
+                continue;
+            }
+            s->busy = true;
+            *out = s;
+            return ZBRA_OK;
+        }
+        Slot *s = new Slot();
+        size_t cap = bytes < 4096 ? 4096 : bytes;
+        hipError_t e = hipHostMalloc(&s->host, cap, hipHostMallocDefault);
+        if (e == hipSuccess) e = hipMalloc(&s->dev, cap);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&s->done, hipEventDisableTiming);
+        if (e != hipSuccess) {
+            if (s->host) (void)hipHostFree(s->host);
+            if (s->dev) (void)hipFree(s->dev);
+            delete s;
+            return hip_status(e);
+        }
+        s->cap = cap;
+        s->busy = true;
+        slots.push_back(s);
+        *out = s;
+        return ZBRA_OK;
+    }
+
+    // Call after the last use of the slot has been enqueued on `stream`.
+    int release(Slot *s, hipStream_t stream) {
+        hipError_t e = hipEventRecord(s->done, stream);
+        std::lock_guard<std::mutex> g(mu);
+        s->busy = false;
+        return hip_status(e);
+    }
+
+    static int grow_dev(Arena &a, size_t bytes) {
+        if (a.cap >= bytes) return ZBRA_OK;
+        if (a.ptr) ZBRA_HIP_TRY(hipFree(a.ptr));
+        a.ptr = nullptr; a.cap = 0;
+        size_t cap = bytes + bytes / 8 + 256;
+        ZBRA_HIP_TRY(hipMalloc(&a.ptr, cap));
+        a.cap = cap;
+        return ZBRA_OK;
+    }
+    static int grow_pinned(Arena &a, size_t bytes) {
+        if (a.cap >= bytes) return ZBRA_OK;
+        if (a.ptr) ZBRA_HIP_TRY(hipHostFree(a.ptr));
+        a.ptr = nullptr; a.cap = 0;
+        ZBRA_HIP_TRY(hipHostMalloc(&a.ptr, bytes, hipHostMallocDefault));
+        a.cap = bytes;
+        return ZBRA_OK;
+    }
+};
+
+// Context of the calling thread's current device (created on first use).
+int current_ctx(DeviceCtx **out);
+
+}  // namespace zbra

@@ -1,0 +1,497 @@
+// Encode kernels: exact median by radix select -> width -> fused (v - mid) -> zig-zag -> bit-pack.
+//
+// Replaces compress_int_array (zbra-core/src/compression.rs:271-292) and its stages
+// frame_of_reference_encode (:52-74, clone + full sort for the median), zig_zag_encode (:88-98)
+// and bp64_pack (:117-178, max scan + byte-at-a-time bit buffer).
+//
+// The bytes are a function of (midpoint, width) only, so the device needs, per array:
+//   1. min / max                                   -> key space [0, span], span = max - min
+//   2. the (n-1)/2-th smallest value a, and for even n the next one b
+//                                                   -> radix select on key = v - min, 12 bits a pass,
+//                                                      ceil(bits(span)/12) passes (1 for spans < 4096)
+//   3. midpoint = a, or a + trunc((b - a)/2)        (compression.rs:60-68)
+//   4. width = bit length of max zigzag(v - mid)    from the two extremes when span < 2^63 (no
+//                                                   wrap-around possible), else from an OR pass
+//   5. the packed stream.
+// Every kernel works on a whole submission (many arrays) through the same tile -> array map the
+// decoder uses, and every pass that an array does not need skips that array's memory.
+#pragma once
+#include "zbra_common.hpp"
+
+namespace zbra {
+
+constexpr int DIGIT_BITS = 12;
+constexpr int BINS = 1 << DIGIT_BITS;
+constexpr int MAX_PASSES = 6;  // ceil(64 / 12)
+constexpr uint64_t SIGN = 0x8000000000000000ull;
+constexpr uint32_t WIDTH_SKIP = 0xFFFFFFFFu;  // array rejected (capacity): pack nothing
+
+// One array of an encode submission: inputs (filled by the host) and select state (device).
+struct EncodeJob {
+    const void *values;  // n elements of `kind`
+    uint8_t *out;        // E goes here
+    uint64_t n;
+    uint64_t cap;
+    uint32_t kind;
+    uint32_t passes;     // radix-select passes this array needs
+    uint64_t min_b;      // min / max of (v ^ SIGN): unsigned order of the biased value = signed order
+    uint64_t max_b;
+    uint64_t prefix;     // resolved high digits of the key of a
+    uint64_t k;          // rank of a among the elements that share `prefix`
+    uint64_t next_above; // smallest key whose high digits exceed `prefix` (last pass)
+    uint64_t or_bits;    // OR of zigzag(v - mid), wide spans only
+    int64_t midpoint;
+    uint32_t width;
+    uint32_t need_or;
+};
+
+__device__ __forceinline__ int64_t load_value(const EncodeJob &j, uint64_t i) {
+    return j.kind != ZBRA_ELEM_U32 ? gptr<int64_t>(j.values)[i] : (int64_t)gptr<uint32_t>(j.values)[i];
+}
+
+// Value that goes into the bit stream: zigzag(v - mid), or v itself for bp64_pack alone.
+__device__ __forceinline__ uint64_t to_stream(const EncodeJob &j, int64_t x, uint64_t mid) {
+    return j.kind == KIND_U64_PLAIN ? (uint64_t)x : zigzag_encode64((int64_t)((uint64_t)x - mid));
+}
+
+// Loads the two values i, i+1 (i even) of a tile; lanes past the end get `fill`.
+__device__ __forceinline__ void load_pair(const EncodeJob &j, uint64_t i, uint64_t n, int64_t fill, int64_t &x0,
+                                          int64_t &x1) {
+    x0 = fill; x1 = fill;
+    if (i + 1 < n) {
+        if (j.kind != ZBRA_ELEM_U32) {
+            const u64x2 v = *(const ZBRA_GLOBAL u64x2 *)(gptr<int64_t>(j.values) + i);  // 16-B load
+            x0 = (int64_t)v.x; x1 = (int64_t)v.y;
+        } else {
+            const u32x2 v = *(const ZBRA_GLOBAL u32x2 *)(gptr<uint32_t>(j.values) + i);
+            x0 = (int64_t)v.x; x1 = (int64_t)v.y;
+        }
+    } else if (i < n) {
+        x0 = load_value(j, i);
+    }
+}
+
+__device__ __forceinline__ uint64_t wave_min_u64(uint64_t v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { uint64_t t = __shfl_xor(v, o); v = t < v ? t : v; }
+    return v;
+}
+__device__ __forceinline__ uint64_t wave_max_u64(uint64_t v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { uint64_t t = __shfl_xor(v, o); v = t > v ? t : v; }
+    return v;
+}
+__device__ __forceinline__ uint64_t wave_or_u64(uint64_t v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v |= __shfl_xor(v, o);
+    return v;
+}
+
+// Walks the contiguous tile range of this workgroup array by array.  F(a, job, first_tile_of_a,
+// t0, t1) is called once per array with tiles [t0, t1) of the submission.
+template <typename F>
+__device__ __forceinline__ void for_each_array_run(const uint64_t *__restrict__ tile_start, uint32_t nd, uint64_t ntiles,
+                                                   F &&f) {
+    const uint64_t tpw = (ntiles + gridDim.x - 1) / gridDim.x;
+    uint64_t t = (uint64_t)blockIdx.x * tpw;
+    uint64_t tend = t + tpw < ntiles ? t + tpw : ntiles;
+    if (t >= tend) return;
+    uint32_t a = nd > 1 ? find_array(tile_start, nd, t) : 0;
+    while (t < tend) {
+        const uint64_t a_first = tile_start[a];
+        const uint64_t a_last = tile_start[a + 1];
+        const uint64_t t1 = a_last < tend ? a_last : tend;
+        if (t1 > t) f(a, a_first, t, t1);
+        t = t1;
+        a++;
+    }
+}
+
+// ---- 1. min / max --------------------------------------------------------------------------
+
+__global__ __launch_bounds__(THREADS) void enc_minmax_kernel(EncodeJob *__restrict__ jobs,
+                                                              const uint64_t *__restrict__ tile_start, uint32_t nd,
+                                                              uint64_t ntiles) {
+    for_each_array_run(tile_start, nd, ntiles, [&](uint32_t a, uint64_t a_first, uint64_t t0, uint64_t t1) {
+        const EncodeJob &job = jobs[a];
+        if (job.kind == KIND_U64_PLAIN) return;
+        const uint64_t n = job.n;
+        uint64_t lo = ~0ull, hi = 0;
+        for (uint64_t t = t0; t < t1; ++t) {
+            const uint64_t v0 = (t - a_first) * TILE;
+#pragma unroll
+            for (int it = 0; it < TILE / (THREADS * 2); ++it) {
+                const uint64_t i = v0 + it * THREADS * 2 + threadIdx.x * 2;
+                if (i < n) {
+                    int64_t x0, x1;
+                    load_pair(job, i, n, 0, x0, x1);
+                    if (i + 1 >= n) x1 = x0;
+                    const uint64_t b0 = (uint64_t)x0 ^ SIGN, b1 = (uint64_t)x1 ^ SIGN;
+                    lo = min(lo, min(b0, b1));
+                    hi = max(hi, max(b0, b1));
+                }
+            }
+        }
+        lo = wave_min_u64(lo);
+        hi = wave_max_u64(hi);
+        if ((threadIdx.x & 63) == 0) {
+            atomicMin((unsigned long long *)&jobs[a].min_b, (unsigned long long)lo);
+            atomicMax((unsigned long long *)&jobs[a].max_b, (unsigned long long)hi);
+        }
+    });
+}
+
+// ---- 2. radix select ---------------------------------------------------------------------
+
+__device__ __forceinline__ uint32_t bit_length64(uint64_t x) { return x ? 64u - (uint32_t)__builtin_clzll(x) : 0u; }
+
+// bp64_pack's width rule (compression.rs:123-128) from max zig-zag value.
+__device__ __forceinline__ uint32_t width_of(uint64_t zmax) { return zmax ? bit_length64(zmax) : 1u; }
+
+__device__ __forceinline__ void set_midpoint(EncodeJob &j, int64_t a, int64_t b, bool even) {
+    int64_t mid = a;
+    if (even) {
+        const int64_t diff = (int64_t)((uint64_t)b - (uint64_t)a);  // b.wrapping_sub(a)
+        mid = (int64_t)((uint64_t)a + (uint64_t)(diff / 2));        // a.wrapping_add(diff / 2), `/` truncates
+    }
+    j.midpoint = mid;
+    if (!j.need_or) {
+        const int64_t vmin = (int64_t)(j.min_b ^ SIGN), vmax = (int64_t)(j.max_b ^ SIGN);
+        const uint64_t z0 = zigzag_encode64((int64_t)((uint64_t)vmin - (uint64_t)mid));
+        const uint64_t z1 = zigzag_encode64((int64_t)((uint64_t)vmax - (uint64_t)mid));
+        j.width = width_of(z0 > z1 ? z0 : z1);
+    }
+}
+
+__global__ void enc_setup_kernel(EncodeJob *__restrict__ jobs, uint32_t nd) {
+    const uint32_t a = blockIdx.x * blockDim.x + threadIdx.x;
+    if (a >= nd) return;
+    EncodeJob &j = jobs[a];
+    if (j.n == 0) { j.passes = 0; return; }
+    if (j.kind == KIND_U64_PLAIN) { j.passes = 0; j.need_or = 1; j.midpoint = 0; return; }
+    const uint64_t span = j.max_b - j.min_b;
+    j.passes = (bit_length64(span) + DIGIT_BITS - 1) / DIGIT_BITS;
+    j.need_or = span >= SIGN;
+    j.k = (j.n - 1) / 2;  // rank of a: n/2 - 1 for even n, n/2 for odd n
+    j.prefix = 0;
+    if (j.passes == 0) {  // constant column
+        const int64_t v = (int64_t)(j.min_b ^ SIGN);
+        set_midpoint(j, v, v, false);
+    }
+}
+
+// Histogram of digit `pass` of the keys that share the resolved prefix.
+__global__ __launch_bounds__(THREADS) void enc_hist_kernel(EncodeJob *__restrict__ jobs,
+                                                            const uint64_t *__restrict__ tile_start, uint32_t nd,
+                                                            uint64_t ntiles, uint32_t *__restrict__ hist, uint32_t pass) {
+    __shared__ uint32_t lh[BINS];
+    for (uint32_t b = threadIdx.x; b < BINS; b += THREADS) lh[b] = 0;
+    __syncthreads();
+    for_each_array_run(tile_start, nd, ntiles, [&](uint32_t a, uint64_t a_first, uint64_t t0, uint64_t t1) {
+        const EncodeJob &job = jobs[a];
+        if (pass >= job.passes) return;  // uniform
+        const uint64_t n = job.n;
+        const uint32_t shift = DIGIT_BITS * (job.passes - 1 - pass);
+        const bool last = pass + 1 == job.passes;
+        const uint64_t prefix = job.prefix;
+        const uint64_t vmin_b = job.min_b;
+        uint64_t above = ~0ull;
+        for (uint64_t t = t0; t < t1; ++t) {
+            const uint64_t v0 = (t - a_first) * TILE;
+#pragma unroll
+            for (int it = 0; it < TILE / (THREADS * 2); ++it) {
+                const uint64_t i = v0 + it * THREADS * 2 + threadIdx.x * 2;
+                if (i < n) {
+                    int64_t x[2];
+                    load_pair(job, i, n, 0, x[0], x[1]);
+                    const int cnt = i + 1 < n ? 2 : 1;
+                    for (int e = 0; e < cnt; e++) {
+                        const uint64_t key = ((uint64_t)x[e] ^ SIGN) - vmin_b;
+                        if (pass == 0) {
+                            atomicAdd(&lh[(uint32_t)(key >> shift)], 1u);
+                        } else {
+                            const uint64_t high = key >> (shift + DIGIT_BITS);
+                            if (high == prefix) atomicAdd(&lh[(uint32_t)(key >> shift) & (BINS - 1)], 1u);
+                            else if (last && high > prefix) above = min(above, key);
+                        }
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        uint32_t *gh = hist + (size_t)a * BINS;
+        for (uint32_t b = threadIdx.x; b < BINS; b += THREADS) {
+            const uint32_t c = lh[b];
+            if (c) { atomicAdd(&gh[b], c); lh[b] = 0; }
+        }
+        if (last && pass > 0) {
+            above = wave_min_u64(above);
+            if ((threadIdx.x & 63) == 0 && above != ~0ull)
+                atomicMin((unsigned long long *)&jobs[a].next_above, (unsigned long long)above);
+        }
+        __syncthreads();
+    });
+}
+
+// One workgroup per array: finds the bin that holds rank k, descends, and on the last pass
+// derives a, b and the midpoint.  Leaves the array's histogram zeroed for the next pass.
+__global__ __launch_bounds__(THREADS) void enc_select_kernel(EncodeJob *__restrict__ jobs, uint32_t *__restrict__ hist,
+                                                              uint32_t pass) {
+    const uint32_t a = blockIdx.x;
+    EncodeJob &job = jobs[a];
+    if (pass >= job.passes) return;
+    __shared__ uint64_t part[THREADS];
+    __shared__ uint32_t sel_bin, next_bin, sel_cnt;
+    __shared__ uint64_t sel_before;
+    uint32_t *gh = hist + (size_t)a * BINS;
+    constexpr int PER = BINS / THREADS;  // 16 consecutive bins per thread
+    const uint32_t tid = threadIdx.x;
+    uint32_t c[PER];
+    uint64_t sum = 0;
+#pragma unroll
+    for (int i = 0; i < PER; i++) { c[i] = gh[tid * PER + i]; sum += c[i]; }
+    part[tid] = sum;
+    if (tid == 0) next_bin = BINS;
+    __syncthreads();
+    // exclusive prefix of the per-thread sums (256 entries: a serial scan by every thread's own
+    // loop would be 256 LDS reads; a Hillis-Steele scan is 8 steps)
+    uint64_t incl = sum;
+    for (int o = 1; o < THREADS; o <<= 1) {
+        uint64_t add = tid >= (uint32_t)o ? part[tid - o] : 0;
+        __syncthreads();
+        incl += add;
+        part[tid] = incl;
+        __syncthreads();
+    }
+    uint64_t before = incl - sum;
+    const uint64_t k = job.k;
+    if (k >= before && k < incl) {  // exactly one thread
+        uint64_t run = before;
+#pragma unroll
+        for (int i = 0; i < PER; i++) {
+            if (k >= run && k < run + c[i]) { sel_bin = tid * PER + i; sel_before = run; sel_cnt = c[i]; }
+            run += c[i];
+        }
+    }
+    __syncthreads();
+    const uint32_t d = sel_bin;
+    const bool last = pass + 1 == job.passes;
+    if (last) {
+#pragma unroll
+        for (int i = 0; i < PER; i++) {
+            const uint32_t b = tid * PER + i;
+            if (b > d && c[i]) { atomicMin(&next_bin, b); break; }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < PER; i++) gh[tid * PER + i] = 0;
+    __syncthreads();
+    if (tid == 0) {
+        const uint64_t high = job.prefix;
+        const uint64_t key_a = pass == 0 ? (uint64_t)d : (high << DIGIT_BITS) | d;
+        const uint64_t k_in = k - sel_before;
+        job.prefix = key_a;
+        job.k = k_in;
+        if (last) {
+            const bool even = (job.n & 1) == 0;
+            uint64_t key_b = key_a;
+            if (even && k_in + 1 >= sel_cnt) {
+                if (next_bin < BINS) key_b = pass == 0 ? (uint64_t)next_bin : (high << DIGIT_BITS) | next_bin;
+                else key_b = job.next_above;
+            }
+            const int64_t va = (int64_t)((key_a + job.min_b) ^ SIGN);
+            const int64_t vb = (int64_t)((key_b + job.min_b) ^ SIGN);
+            set_midpoint(job, va, vb, even);
+        }
+    }
+}
+
+// ---- 4. width of wide-span arrays -------------------------------------------------------------
+
+__global__ __launch_bounds__(THREADS) void enc_or_kernel(EncodeJob *__restrict__ jobs,
+                                                          const uint64_t *__restrict__ tile_start, uint32_t nd,
+                                                          uint64_t ntiles) {
+    for_each_array_run(tile_start, nd, ntiles, [&](uint32_t a, uint64_t a_first, uint64_t t0, uint64_t t1) {
+        const EncodeJob &job = jobs[a];
+        if (!job.need_or) return;
+        const uint64_t n = job.n;
+        const uint64_t mid = (uint64_t)job.midpoint;
+        uint64_t acc = 0;
+        for (uint64_t t = t0; t < t1; ++t) {
+            const uint64_t v0 = (t - a_first) * TILE;
+#pragma unroll
+            for (int it = 0; it < TILE / (THREADS * 2); ++it) {
+                const uint64_t i = v0 + it * THREADS * 2 + threadIdx.x * 2;
+                if (i < n) {
+                    int64_t x0, x1;
+                    load_pair(job, i, n, (int64_t)mid, x0, x1);  // fill = mid -> contributes 0 (mid = 0 when plain)
+                    acc |= to_stream(job, x0, mid) | to_stream(job, x1, mid);
+                }
+            }
+        }
+        acc = wave_or_u64(acc);
+        if ((threadIdx.x & 63) == 0 && acc) atomicOr((unsigned long long *)&jobs[a].or_bits, (unsigned long long)acc);
+    });
+}
+
+// ---- 5. header + pack ----------------------------------------------------------------------
+
+// Writes midpoint | packed_len | width (compression.rs:131, 287-288) and the result words.
+__global__ void enc_finalize_kernel(EncodeJob *__restrict__ jobs, uint32_t nd, zbra_dev_result *results) {
+    const uint32_t a = blockIdx.x * blockDim.x + threadIdx.x;
+    if (a >= nd) return;
+    EncodeJob &j = jobs[a];
+    zbra_dev_result r;
+    r.status = ZBRA_OK; r.width = 0; r.out_count = 0; r.midpoint = 0; r.packed_len = 0;
+    if (j.n == 0) {                       // compression.rs:272-274: empty in, empty out
+        j.width = WIDTH_SKIP;
+    } else {
+        if (j.need_or) j.width = width_of(j.or_bits);
+        const uint32_t w = j.width;
+        const uint64_t payload = w >= 32 ? j.n * 8 : (j.n * w + 7) / 8;
+        const uint64_t packed_len = 1 + payload;
+        r.width = w; r.midpoint = j.midpoint; r.packed_len = packed_len; r.out_count = 12 + packed_len;
+        if (j.cap < 12 + packed_len) {
+            r.status = ZBRA_ERR_CAPACITY; r.out_count = 0;
+            j.width = WIDTH_SKIP;
+        } else {
+            const uint64_t m = (uint64_t)j.midpoint;
+            for (int b = 0; b < 8; b++) j.out[b] = (uint8_t)(m >> (8 * b));
+            const uint32_t pl = (uint32_t)packed_len;  // `as u32`, compression.rs:288
+            for (int b = 0; b < 4; b++) j.out[8 + b] = (uint8_t)(pl >> (8 * b));
+            j.out[12] = (uint8_t)w;
+        }
+    }
+    if (results) results[a] = r;
+}
+
+// Bits [lo, lo + 32) of a tile's packed stream, lo possibly negative or past the end; zz holds
+// the tile's zig-zag values (0 past the last value).  inv = ceil(2^32 / w).
+__device__ __forceinline__ uint32_t stream_dword(const uint32_t *zz, int32_t lo, uint32_t w, uint64_t inv) {
+    int32_t i, pos;  // value i starts at bit pos relative to lo
+    if (lo <= 0) { i = 0; pos = -lo; }
+    else { i = (int32_t)(((uint64_t)(uint32_t)lo * inv) >> 32); pos = i * (int32_t)w - lo; }
+    uint32_t acc = 0;
+    while (pos < 32 && i < TILE) {
+        const uint32_t z = zz[i];
+        acc |= pos >= 0 ? z << pos : z >> (-pos);
+        pos += (int32_t)w;
+        i++;
+    }
+    return acc;
+}
+
+__device__ __forceinline__ void pack_tile_packed(const EncodeJob &job, uint64_t v0, uint32_t nv, uint32_t *zz) {
+    const uint32_t tid = threadIdx.x;
+    const uint32_t w = job.width;
+    const uint64_t mid = (uint64_t)job.midpoint;
+    // stage zig-zag values (all below 2^31 because w <= 31)
+#pragma unroll
+    for (int it = 0; it < TILE / (THREADS * 2); ++it) {
+        const uint32_t j = it * THREADS * 2 + tid * 2;
+        int64_t x0, x1;
+        load_pair(job, v0 + j, v0 + nv, (int64_t)mid, x0, x1);
+        uint2 z;
+        z.x = (uint32_t)to_stream(job, x0, mid);
+        z.y = (uint32_t)to_stream(job, x1, mid);
+        *(uint2 *)(zz + j) = z;
+    }
+    __syncthreads();
+    const uintptr_t G = (uintptr_t)job.out + 13 + ((v0 * w) >> 3);
+    const uint32_t nbytes = (nv * w + 7u) >> 3;
+    const uintptr_t Gend = G + nbytes;
+    const uintptr_t G0 = G & ~(uintptr_t)15;
+    const uint32_t off = (uint32_t)(G - G0);
+    const uint32_t nchunks = (off + nbytes + 15u) >> 4;
+    const uint64_t inv = (0x100000000ull + w - 1) / w;
+    for (uint32_t c = tid; c < nchunks; c += THREADS) {
+        const int32_t lo = (int32_t)(c * 128u) - (int32_t)(off * 8u);
+        u32x4 v;
+        v.x = stream_dword(zz, lo, w, inv);
+        v.y = stream_dword(zz, lo + 32, w, inv);
+        v.z = stream_dword(zz, lo + 64, w, inv);
+        v.w = stream_dword(zz, lo + 96, w, inv);
+        const uintptr_t addr = G0 + (uintptr_t)c * 16;
+        if (addr >= G && addr + 16 <= Gend) {
+            *gptr_mut<u32x4>(addr) = v;
+        } else {  // head / tail chunk shared with a neighbour: only this tile's bytes
+            const uint32_t d[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int b = 0; b < 16; b++) {
+                const uintptr_t p = addr + b;
+                if (p >= G && p < Gend) *gptr_mut<uint8_t>(p) = (uint8_t)(d[b >> 2] >> (8 * (b & 3)));
+            }
+        }
+    }
+    __syncthreads();
+}
+
+// Raw fallback: zig-zag value i as u64 LE at payload + 8*i (compression.rs:143-149).
+__device__ __forceinline__ void pack_tile_raw(const EncodeJob &job, uint64_t v0, uint32_t nv) {
+    const uint32_t tid = threadIdx.x;
+    const uint64_t mid = (uint64_t)job.midpoint;
+    const uintptr_t G = (uintptr_t)job.out + 13 + v0 * 8;
+    const uint32_t nbytes = nv * 8u;
+    const uintptr_t Gend = G + nbytes;
+    const uintptr_t G0 = G & ~(uintptr_t)15;
+    const uint32_t off = (uint32_t)(G - G0);
+    const uint32_t nchunks = (off + nbytes + 15u) >> 4;
+    for (uint32_t c = tid; c < nchunks; c += THREADS) {
+        const int32_t lo_byte = (int32_t)(c * 16u) - (int32_t)off;
+        const int32_t i0 = lo_byte >> 3;  // floor
+        const uint32_t sub = (uint32_t)(lo_byte - i0 * 8) * 8u;  // bit offset inside value i0
+        uint64_t z[3];
+#pragma unroll
+        for (int e = 0; e < 3; e++) {
+            const int32_t i = i0 + e;
+            z[e] = 0;
+            if (i >= 0 && (uint32_t)i < nv)
+                z[e] = to_stream(job, load_value(job, v0 + (uint32_t)i), mid);
+        }
+        uint64_t o0 = z[0], o1 = z[1];
+        if (sub) {
+            o0 = (z[0] >> sub) | (z[1] << (64 - sub));
+            o1 = (z[1] >> sub) | (z[2] << (64 - sub));
+        }
+        const uintptr_t addr = G0 + (uintptr_t)c * 16;
+        if (addr >= G && addr + 16 <= Gend) {
+            u64x2 v = {o0, o1};
+            *gptr_mut<u64x2>(addr) = v;
+        } else {
+#pragma unroll
+            for (int b = 0; b < 16; b++) {
+                const uintptr_t p = addr + b;
+                const uint64_t src = b < 8 ? o0 : o1;
+                if (p >= G && p < Gend) *gptr_mut<uint8_t>(p) = (uint8_t)(src >> (8 * (b & 7)));
+            }
+        }
+    }
+}
+
+// frame_of_reference_encode alone: copies each array's midpoint to its result words.
+__global__ void enc_report_median_kernel(const EncodeJob *__restrict__ jobs, uint32_t nd, zbra_dev_result *results) {
+    const uint32_t a = blockIdx.x * blockDim.x + threadIdx.x;
+    if (a >= nd) return;
+    zbra_dev_result r;
+    r.status = ZBRA_OK; r.width = jobs[a].need_or ? 0 : jobs[a].width; r.out_count = jobs[a].n;
+    r.midpoint = jobs[a].midpoint; r.packed_len = 0;
+    results[a] = r;
+}
+
+__global__ __launch_bounds__(THREADS) void enc_pack_kernel(const EncodeJob *__restrict__ jobs,
+                                                            const uint64_t *__restrict__ tile_start, uint32_t nd,
+                                                            uint64_t ntiles) {
+    __shared__ __attribute__((aligned(16))) uint32_t zz[TILE];
+    for (uint64_t t = blockIdx.x; t < ntiles; t += gridDim.x) {
+        const uint32_t a = nd > 1 ? find_array(tile_start, nd, t) : 0;
+        const EncodeJob &job = jobs[a];
+        if (job.width == WIDTH_SKIP) continue;
+        const uint64_t v0 = (t - tile_start[a]) * TILE;
+        const uint64_t left = job.n - v0;
+        const uint32_t nv = left < (uint64_t)TILE ? (uint32_t)left : (uint32_t)TILE;
+        if (job.width < 32) pack_tile_packed(job, v0, nv, zz);
+        else pack_tile_raw(job, v0, nv);
+    }
+}
+
+}  // namespace zbra

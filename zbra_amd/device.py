@@ -1,0 +1,108 @@
+"""Device-resident entry points of libzbra_hip.so on torch tensors.
+
+torch supplies device memory and the stream; every byte of codec work is done by the library's
+HIP kernels.  Calls are stream-ordered on torch's current stream and do not synchronise.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib
+from ._lib import ArrayDesc, DevResult, EncodeDesc, lib
+from .compression import _raise
+
+RESULT_BYTES = C.sizeof(DevResult)  # 32
+
+
+def _stream_handle(stream=None):
+    s = stream if stream is not None else torch.cuda.current_stream()
+    return C.c_void_p(s.cuda_stream)
+
+
+def encode_bound(n: int) -> int:
+    return lib.zbra_hip_encode_bound(n)
+
+
+def new_results(n: int, device) -> torch.Tensor:
+    """Device buffer for n zbra_dev_result records."""
+    return torch.zeros(n * RESULT_BYTES, dtype=torch.uint8, device=device)
+
+
+def read_results(results: torch.Tensor):
+    """Copies result records to the host (synchronises) and returns a list of DevResult."""
+    raw = results.cpu().numpy().tobytes()
+    n = len(raw) // RESULT_BYTES
+    return [DevResult.from_buffer_copy(raw, i * RESULT_BYTES) for i in range(n)]
+
+
+def _kind_of(dtype) -> int:
+    if dtype == torch.int64:
+        return _lib.ELEM_I64
+    if dtype in (torch.uint32, torch.int32):
+        return _lib.ELEM_U32
+    raise TypeError(f"unsupported element dtype {dtype}")
+
+
+def decode_dev(encoded: torch.Tensor, count: int, out: torch.Tensor, result: torch.Tensor = None, length: int = None,
+               stream=None):
+    """decompress_int_array (compression.rs:295-330) on bytes resident in HBM.
+
+    encoded: uint8 CUDA tensor holding E; out: int64 (or int32/uint32 for tag arrays) CUDA tensor
+    of `count` elements; result: optional uint8 tensor of RESULT_BYTES bytes."""
+    assert encoded.is_cuda and encoded.dtype == torch.uint8 and encoded.is_contiguous()
+    assert out.is_cuda and out.is_contiguous() and out.numel() >= count
+    n = encoded.numel() if length is None else length
+    st = lib.zbra_hip_decode_dev(encoded.data_ptr(), n, count, out.data_ptr(), _kind_of(out.dtype),
+                                 result.data_ptr() if result is not None else None, _stream_handle(stream))
+    if st:
+        _raise(st)
+
+
+def make_descs(items):
+    """items: iterable of (data_ptr, len, count, out_ptr, kind) -> ctypes array of zbra_array_desc."""
+    items = list(items)
+    arr = (ArrayDesc * len(items))()
+    for i, (dp, ln, cnt, op, kind) in enumerate(items):
+        arr[i].data = dp
+        arr[i].len = ln
+        arr[i].count = cnt
+        arr[i].out = op
+        arr[i].kind = kind
+    return arr
+
+
+def decode_batch_dev(descs, results: torch.Tensor = None, stream=None):
+    """Decodes many independent arrays in one submission; descs from make_descs()."""
+    st = lib.zbra_hip_decode_batch_dev(descs, len(descs), results.data_ptr() if results is not None else None,
+                                       _stream_handle(stream))
+    if st:
+        _raise(st)
+
+
+def encode_dev(values: torch.Tensor, out: torch.Tensor, result: torch.Tensor, stream=None):
+    """compress_int_array (compression.rs:271-292) on values resident in HBM; the encoded length
+    lands in result (out_count)."""
+    assert values.is_cuda and values.is_contiguous() and out.is_cuda and out.dtype == torch.uint8
+    st = lib.zbra_hip_encode_dev(values.data_ptr(), values.numel(), _kind_of(values.dtype), out.data_ptr(), out.numel(),
+                                 result.data_ptr(), _stream_handle(stream))
+    if st:
+        _raise(st)
+
+
+def make_encode_descs(items):
+    """items: iterable of (values_ptr, n, out_ptr, cap, kind) -> ctypes array of zbra_encode_desc."""
+    items = list(items)
+    arr = (EncodeDesc * len(items))()
+    for i, (vp, n, op, cap, kind) in enumerate(items):
+        arr[i].values = vp
+        arr[i].n = n
+        arr[i].out = op
+        arr[i].cap = cap
+        arr[i].kind = kind
+    return arr
+
+
+def encode_batch_dev(descs, results: torch.Tensor, stream=None):
+    st = lib.zbra_hip_encode_batch_dev(descs, len(descs), results.data_ptr(), _stream_handle(stream))
+    if st:
+        _raise(st)

@@ -1,0 +1,60 @@
+"""Synthetic columns of the benchmark configurations, generated in place on the device.
+
+Counter-based splitmix64, sm(seed, i) = finalise(seed + (i+1)*0x9E3779B97F4A7C15): the same value
+for index i on the CPU, in numpy and here, so multi-GB inputs never cross PCIe.  torch has no
+unsigned 64-bit arithmetic; int64 multiplication wraps and logical shifts are masked arithmetic
+shifts, which gives the same bits.
+"""
+import torch
+
+_M64 = (1 << 64) - 1
+
+
+def _s(x: int) -> int:
+    """Python int -> the int64 with the same low 64 bits."""
+    x &= _M64
+    return x - (1 << 64) if x >> 63 else x
+
+
+_GOLDEN = _s(0x9E3779B97F4A7C15)
+_C1 = _s(0xBF58476D1CE4E5B9)
+_C2 = _s(0x94D049BB133111EB)
+
+
+def _lsr(z: torch.Tensor, s: int) -> torch.Tensor:
+    return (z >> s) & ((1 << (64 - s)) - 1)
+
+
+def sm(seed: int, idx: torch.Tensor) -> torch.Tensor:
+    """splitmix64 of int64 index tensor `idx`; result holds the u64 value's bits as int64."""
+    z = (idx + 1) * _GOLDEN + _s(seed)
+    z = (z ^ _lsr(z, 30)) * _C1
+    z = (z ^ _lsr(z, 27)) * _C2
+    return z ^ _lsr(z, 31)
+
+
+def umod(z: torch.Tensor, m: int) -> torch.Tensor:
+    """(z as u64) mod m for m < 2^31."""
+    return ((_lsr(z, 1) % m) * 2 + (z & 1)) % m
+
+
+def narrow_column(seed: int, first: int, n: int, device, chunk: int = 1 << 24) -> torch.Tensor:
+    """Headline column: v[i] = 1.7e12 + sm(seed, first + i) mod 4000  (bit width 12 after FOR)."""
+    out = torch.empty(n, dtype=torch.int64, device=device)
+    for s in range(0, n, chunk):
+        e = min(n, s + chunk)
+        idx = torch.arange(first + s, first + e, dtype=torch.int64, device=device)
+        out[s:e] = umod(sm(seed, idx), 4000) + 1_700_000_000_000
+    return out
+
+
+def mixed_width_chunk(c: int, first: int, n: int, device) -> torch.Tensor:
+    """Chunk c of the mixed-width stress column: signed 48-bit base b_c, amplitude a_c in 1..40
+    bits, v = b_c + (sm(0x5EED2003, i) mod 2^a_c) - 2^(a_c-1)."""
+    cidx = torch.tensor([c], dtype=torch.int64, device=device)
+    base = int(sm(0x5EED0003, cidx).item())
+    base = ((base & ((1 << 48) - 1)) ^ (1 << 47)) - (1 << 47)  # sign-extend 48 bits
+    a = 1 + int(umod(sm(0x5EED1003, cidx), 40).item())
+    idx = torch.arange(first, first + n, dtype=torch.int64, device=device)
+    r = sm(0x5EED2003, idx) & ((1 << a) - 1)
+    return r - (1 << (a - 1)) + base
