@@ -88,7 +88,7 @@ def test_decode_batch_mixed(env):
     encs.append(oc.compress_int_array(tags.astype(np.int64)))
     kinds.append(L.ELEM_U32)
     # a rejected array in the middle of the batch must not disturb its neighbours
-    bad_at = 7
+    bad_at = 4
     blob = bytearray()
     offs = []
     for e in encs:
