@@ -2,6 +2,7 @@
 // zbra_decode.hpp / zbra_encode.hpp / zbra_stages.hpp.  gfx950 only; there is no CPU path.
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <mutex>
@@ -40,7 +41,19 @@ static inline uint64_t tiles_of(uint64_t count) { return (count + TILE - 1) / TI
 static inline unsigned grid_for(uint64_t ntiles, unsigned cap) { return (unsigned)(ntiles < cap ? (ntiles ? ntiles : 1) : cap); }
 static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
-constexpr unsigned DECODE_GRID_CAP = 256 * 8;  // 8 workgroups of 4 waves per CU
+// Decode grid cap.  One workgroup per tile measured fastest on MI355X (2^28 rows, width 12:
+// 0.434 ms at 131072 workgroups against 0.498 ms for a 2048-workgroup grid-stride loop): short
+// workgroups let the dispatcher keep every CU's queue of outstanding stores full.
+// ZBRA_HIP_DECODE_GRID overrides it (tuning aid).
+static unsigned decode_grid_cap() {
+    static const unsigned cap = [] {
+        const char *e = getenv("ZBRA_HIP_DECODE_GRID");
+        const long v = e ? atol(e) : 0;
+        return v > 0 ? (unsigned)v : 0x7FFFFFFFu;
+    }();
+    return cap;
+}
+#define DECODE_GRID_CAP decode_grid_cap()
 constexpr unsigned STREAM_GRID_CAP = 256 * 8;
 constexpr unsigned HIST_GRID_CAP = 256 * 4;    // 16 KiB of LDS histogram per workgroup
 
