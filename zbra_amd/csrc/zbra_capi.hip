@@ -2,6 +2,7 @@
 // zbra_decode.hpp / zbra_encode.hpp / zbra_stages.hpp.  gfx950 only; there is no CPU path.
 #include <hip/hip_runtime.h>
 
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <map>
@@ -37,25 +38,91 @@ int current_ctx(DeviceCtx **out) {
     return ZBRA_OK;
 }
 
-static inline uint64_t tiles_of(uint64_t count) { return (count + TILE - 1) / TILE; }
+static inline uint64_t tiles_of(uint64_t count) { return (count + TILE - 1) / TILE; }  // encode tiles
 static inline unsigned grid_for(uint64_t ntiles, unsigned cap) { return (unsigned)(ntiles < cap ? (ntiles ? ntiles : 1) : cap); }
 static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
-// Decode grid cap.  One workgroup per tile measured fastest on MI355X (2^28 rows, width 12:
-// 0.434 ms at 131072 workgroups against 0.498 ms for a 2048-workgroup grid-stride loop): short
-// workgroups let the dispatcher keep every CU's queue of outstanding stores full.
-// ZBRA_HIP_DECODE_GRID overrides it (tuning aid).
-static unsigned decode_grid_cap() {
+// Decode kernel configuration: values per tile, threads per workgroup, nontemporal accesses,
+// LDS-free reads, grid cap.  The defaults are the fastest measured on MI355X;
+// ZBRA_HIP_DECODE_VARIANT="tile:threads:nt:direct" and ZBRA_HIP_DECODE_GRID override them
+// (tuning aids).
+struct DecodeConfig {
+    int tile = 1024;
+    int threads = 256;
+    int nt = 1;
+    int direct = 0;
+    int xcd = 1;  // XCD-chunked tile order
+    unsigned grid_cap = 0x7FFFFFFFu;  // one workgroup per tile
+};
+
+template <int DT, int TH>
+static void launch_decode_t(const DecodeConfig &c, unsigned grid, hipStream_t stream, const DecodePlan *plans,
+                            const uint64_t *ts, uint32_t nd, uint64_t ntiles) {
+    const dim3 g(grid), b(TH);
+    const uint32_t x = (c.xcd && (uint64_t)grid == ntiles && ntiles >= 64) ? 1u : 0u;
+    if (c.nt) {
+        if (c.direct) hipLaunchKernelGGL((decode_tiles_kernel<DT, TH, true, true>), g, b, 0, stream, plans, ts, nd, ntiles, x);
+        else hipLaunchKernelGGL((decode_tiles_kernel<DT, TH, true, false>), g, b, 0, stream, plans, ts, nd, ntiles, x);
+    } else {
+        if (c.direct) hipLaunchKernelGGL((decode_tiles_kernel<DT, TH, false, true>), g, b, 0, stream, plans, ts, nd, ntiles, x);
+        else hipLaunchKernelGGL((decode_tiles_kernel<DT, TH, false, false>), g, b, 0, stream, plans, ts, nd, ntiles, x);
+    }
+}
+
+typedef void (*DecodeLauncher)(const DecodeConfig &, unsigned, hipStream_t, const DecodePlan *, const uint64_t *, uint32_t,
+                               uint64_t);
+struct DecodeShape { int tile, threads; DecodeLauncher fn; };
+static const DecodeShape kDecodeShapes[] = {
+    {2048, 256, launch_decode_t<2048, 256>}, {1024, 256, launch_decode_t<1024, 256>}, {4096, 256, launch_decode_t<4096, 256>},
+    {512, 64, launch_decode_t<512, 64>},     {1024, 64, launch_decode_t<1024, 64>},   {2048, 64, launch_decode_t<2048, 64>},
+    {512, 128, launch_decode_t<512, 128>},   {1024, 128, launch_decode_t<1024, 128>}, {2048, 128, launch_decode_t<2048, 128>},
+    {2048, 512, launch_decode_t<2048, 512>}, {4096, 512, launch_decode_t<4096, 512>}, {1024, 512, launch_decode_t<1024, 512>},
+    {2048, 1024, launch_decode_t<2048, 1024>}, {4096, 1024, launch_decode_t<4096, 1024>},
+};
+
+static DecodeLauncher g_decode_fn = launch_decode_t<1024, 256>;
+static const DecodeConfig &decode_config() {
+    static const DecodeConfig cfg = [] {
+        DecodeConfig c;
+        if (const char *e = getenv("ZBRA_HIP_DECODE_VARIANT")) {
+            int t = 0, th = 0, n = 0, d = 0;
+            if (sscanf(e, "%d:%d:%d:%d", &t, &th, &n, &d) == 4) {
+                for (const DecodeShape &sh : kDecodeShapes)
+                    if (sh.tile == t && sh.threads == th) {
+                        c.tile = t; c.threads = th; c.nt = n != 0; c.direct = d != 0;
+                        g_decode_fn = sh.fn;
+                    }
+            }
+        }
+        if (const char *e = getenv("ZBRA_HIP_DECODE_XCD")) c.xcd = atoi(e) != 0;
+        if (const char *e = getenv("ZBRA_HIP_DECODE_GRID")) {
+            const long v = atol(e);
+            if (v > 0) c.grid_cap = (unsigned)v;
+        }
+        return c;
+    }();
+    return cfg;
+}
+static inline uint64_t decode_tiles_of(uint64_t count) {
+    const uint64_t t = (uint64_t)decode_config().tile;
+    return (count + t - 1) / t;
+}
+static void launch_decode(hipStream_t stream, const DecodePlan *plans, const uint64_t *ts, uint32_t nd, uint64_t ntiles) {
+    const DecodeConfig &c = decode_config();
+    g_decode_fn(c, grid_for(ntiles, c.grid_cap), stream, plans, ts, nd, ntiles);
+}
+
+constexpr unsigned STREAM_GRID_CAP = 256 * 8;
+constexpr unsigned HIST_GRID_CAP = 256 * 4;    // 16 KiB of LDS histogram per workgroup
+
+static unsigned pack_grid_cap() {
     static const unsigned cap = [] {
-        const char *e = getenv("ZBRA_HIP_DECODE_GRID");
+        const char *e = getenv("ZBRA_HIP_PACK_GRID");
         const long v = e ? atol(e) : 0;
-        return v > 0 ? (unsigned)v : 0x7FFFFFFFu;
+        return v > 0 ? (unsigned)v : 0x7FFFFFFFu;  // one workgroup per tile, as in decode
     }();
     return cap;
 }
-#define DECODE_GRID_CAP decode_grid_cap()
-constexpr unsigned STREAM_GRID_CAP = 256 * 8;
-constexpr unsigned HIST_GRID_CAP = 256 * 4;    // 16 KiB of LDS histogram per workgroup
 
 // ---- decode, device-resident ---------------------------------------------------------------
 
@@ -69,16 +136,14 @@ static int decode_batch_dev(DeviceCtx *ctx, const zbra_array_desc *descs, size_t
         if ((d.len && !d.data) || (d.count && d.len && !d.out)) return ZBRA_ERR_INVALID_ARG;
     }
     if (nd == 1) {
-        const uint64_t ntiles = tiles_of(descs[0].count);
+        const uint64_t ntiles = decode_tiles_of(descs[0].count);
         Slot *s;
         ZBRA_TRY(ctx->acquire(256, &s));
         DecodePlan *plan = (DecodePlan *)s->dev;
         uint64_t *tile_start = (uint64_t *)((char *)s->dev + 64);
         hipLaunchKernelGGL(plan_decode_one_kernel, dim3(1), dim3(64), 0, stream, descs[0], ntiles, plan, tile_start,
                            d_results);
-        if (ntiles)
-            hipLaunchKernelGGL(decode_tiles_kernel, dim3(grid_for(ntiles, DECODE_GRID_CAP)), dim3(THREADS), 0, stream,
-                               plan, tile_start, 1u, ntiles);
+        if (ntiles) launch_decode(stream, plan, tile_start, 1u, ntiles);
         int st = hip_status(hipGetLastError());
         int st2 = ctx->release(s, stream);
         return st != ZBRA_OK ? st : st2;
@@ -91,7 +156,7 @@ static int decode_batch_dev(DeviceCtx *ctx, const zbra_array_desc *descs, size_t
     std::memcpy(s->host, descs, nd * sizeof(zbra_array_desc));
     uint64_t *h_ts = (uint64_t *)((char *)s->host + off_ts);
     uint64_t run = 0;
-    for (size_t i = 0; i < nd; i++) { h_ts[i] = run; run += tiles_of(descs[i].count); }
+    for (size_t i = 0; i < nd; i++) { h_ts[i] = run; run += decode_tiles_of(descs[i].count); }
     h_ts[nd] = run;
     const uint64_t ntiles = run;
     int st = hip_status(hipMemcpyAsync(s->dev, s->host, off_ts + (nd + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, stream));
@@ -101,9 +166,7 @@ static int decode_batch_dev(DeviceCtx *ctx, const zbra_array_desc *descs, size_t
         DecodePlan *d_plans = (DecodePlan *)((char *)s->dev + off_plan);
         hipLaunchKernelGGL(plan_decode_batch_kernel, dim3((unsigned)((nd + 255) / 256)), dim3(256), 0, stream, d_descs,
                            (uint32_t)nd, d_plans, d_results);
-        if (ntiles)
-            hipLaunchKernelGGL(decode_tiles_kernel, dim3(grid_for(ntiles, DECODE_GRID_CAP)), dim3(THREADS), 0, stream,
-                               d_plans, d_ts, (uint32_t)nd, ntiles);
+        if (ntiles) launch_decode(stream, d_plans, d_ts, (uint32_t)nd, ntiles);
         st = hip_status(hipGetLastError());
     }
     int st2 = ctx->release(s, stream);
@@ -172,7 +235,8 @@ static int encode_batch_dev(DeviceCtx *ctx, const EncodeItem *items, size_t nd, 
         if (mode == ENCODE_FULL) {
             hipLaunchKernelGGL(enc_finalize_kernel, dim3(ga), dim3(256), 0, stream, d_jobs, (uint32_t)nd, d_results);
             if (ntiles)
-                hipLaunchKernelGGL(enc_pack_kernel, dim3(gs), dim3(THREADS), 0, stream, d_jobs, d_ts, (uint32_t)nd, ntiles);
+                hipLaunchKernelGGL(enc_pack_kernel, dim3(grid_for(ntiles, pack_grid_cap())), dim3(THREADS), 0, stream, d_jobs, d_ts,
+                                   (uint32_t)nd, ntiles);
         } else {
             hipLaunchKernelGGL(enc_report_median_kernel, dim3(ga), dim3(256), 0, stream, d_jobs, (uint32_t)nd, d_results);
         }
@@ -414,13 +478,12 @@ int zbra_hip_bp64_unpack(const uint8_t *packed, size_t packed_len, size_t count,
     ZBRA_TRY(DeviceCtx::grow_dev(ctx->dev_out, count * 8));
     ZBRA_HIP_TRY(hipMemcpyAsync(ctx->dev_in.ptr, packed, packed_len, hipMemcpyHostToDevice, ctx->stream));
     ZBRA_TRY(DeviceCtx::grow_dev(ctx->dev_tmp, 256));
-    const uint64_t ntiles = tiles_of(count);
+    const uint64_t ntiles = decode_tiles_of(count);
     DecodePlan *plan = (DecodePlan *)ctx->dev_tmp.ptr;
     uint64_t *tile_start = (uint64_t *)((char *)ctx->dev_tmp.ptr + 64);
     hipLaunchKernelGGL(plan_unpack_kernel, dim3(1), dim3(64), 0, ctx->stream, (const uint8_t *)ctx->dev_in.ptr,
                        (uint64_t)packed_len, (uint64_t)count, ctx->dev_out.ptr, ntiles, plan, tile_start);
-    hipLaunchKernelGGL(decode_tiles_kernel, dim3(grid_for(ntiles, DECODE_GRID_CAP)), dim3(THREADS), 0, ctx->stream, plan,
-                       tile_start, 1u, ntiles);
+    launch_decode(ctx->stream, plan, tile_start, 1u, ntiles);
     ZBRA_HIP_TRY(hipGetLastError());
     ZBRA_HIP_TRY(hipMemcpyAsync(out, ctx->dev_out.ptr, count * 8, hipMemcpyDeviceToHost, ctx->stream));
     ZBRA_HIP_TRY(hipStreamSynchronize(ctx->stream));

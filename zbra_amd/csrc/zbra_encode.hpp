@@ -71,6 +71,35 @@ __device__ __forceinline__ void load_pair(const EncodeJob &j, uint64_t i, uint64
     }
 }
 
+constexpr int PAIRS = TILE / (THREADS * 2);  // 16-B loads per thread per tile
+
+// This thread's 2*PAIRS values of the tile that starts at value v0: x[2*it], x[2*it+1] are values
+// v0 + it*2*THREADS + 2*tid (+1).  A tile that lies wholly inside the array issues all its loads
+// back to back; values past n get `fill`.
+__device__ __forceinline__ void load_tile(const EncodeJob &j, uint64_t v0, uint64_t n, int64_t fill, int64_t (&x)[2 * PAIRS]) {
+    const uint32_t tid = threadIdx.x;
+    if (v0 + TILE <= n) {  // uniform
+        if (j.kind != ZBRA_ELEM_U32) {
+            const ZBRA_GLOBAL u64x2 *src = (const ZBRA_GLOBAL u64x2 *)(gptr<int64_t>(j.values) + v0) + tid;
+            u64x2 v[PAIRS];
+#pragma unroll
+            for (int it = 0; it < PAIRS; ++it) v[it] = __builtin_nontemporal_load(src + it * THREADS);
+#pragma unroll
+            for (int it = 0; it < PAIRS; ++it) { x[2 * it] = (int64_t)v[it].x; x[2 * it + 1] = (int64_t)v[it].y; }
+        } else {
+            const ZBRA_GLOBAL u32x2 *src = (const ZBRA_GLOBAL u32x2 *)(gptr<uint32_t>(j.values) + v0) + tid;
+            u32x2 v[PAIRS];
+#pragma unroll
+            for (int it = 0; it < PAIRS; ++it) v[it] = __builtin_nontemporal_load(src + it * THREADS);
+#pragma unroll
+            for (int it = 0; it < PAIRS; ++it) { x[2 * it] = (int64_t)v[it].x; x[2 * it + 1] = (int64_t)v[it].y; }
+        }
+    } else {
+#pragma unroll
+        for (int it = 0; it < PAIRS; ++it) load_pair(j, v0 + it * THREADS * 2 + tid * 2, n, fill, x[2 * it], x[2 * it + 1]);
+    }
+}
+
 __device__ __forceinline__ uint64_t wave_min_u64(uint64_t v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) { uint64_t t = __shfl_xor(v, o); v = t < v ? t : v; }
@@ -119,24 +148,24 @@ __global__ __launch_bounds__(THREADS) void enc_minmax_kernel(EncodeJob *__restri
         uint64_t lo = ~0ull, hi = 0;
         for (uint64_t t = t0; t < t1; ++t) {
             const uint64_t v0 = (t - a_first) * TILE;
+            int64_t x[2 * PAIRS];
+            // fill = the array's first value: a no-op for both min and max
+            load_tile(job, v0, n, load_value(job, 0), x);
 #pragma unroll
-            for (int it = 0; it < TILE / (THREADS * 2); ++it) {
-                const uint64_t i = v0 + it * THREADS * 2 + threadIdx.x * 2;
-                if (i < n) {
-                    int64_t x0, x1;
-                    load_pair(job, i, n, 0, x0, x1);
-                    if (i + 1 >= n) x1 = x0;
-                    const uint64_t b0 = (uint64_t)x0 ^ SIGN, b1 = (uint64_t)x1 ^ SIGN;
-                    lo = min(lo, min(b0, b1));
-                    hi = max(hi, max(b0, b1));
-                }
+            for (int e = 0; e < 2 * PAIRS; ++e) {
+                const uint64_t b = (uint64_t)x[e] ^ SIGN;
+                lo = min(lo, b);
+                hi = max(hi, b);
             }
         }
         lo = wave_min_u64(lo);
         hi = wave_max_u64(hi);
         if ((threadIdx.x & 63) == 0) {
-            atomicMin((unsigned long long *)&jobs[a].min_b, (unsigned long long)lo);
-            atomicMax((unsigned long long *)&jobs[a].max_b, (unsigned long long)hi);
+            // most waves cannot improve on what is already there: look before adding to the queue
+            // on these two words (a stale look only costs an atomic that changes nothing)
+            unsigned long long *pmin = (unsigned long long *)&jobs[a].min_b, *pmax = (unsigned long long *)&jobs[a].max_b;
+            if (lo < __hip_atomic_load(pmin, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMin(pmin, (unsigned long long)lo);
+            if (hi > __hip_atomic_load(pmax, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(pmax, (unsigned long long)hi);
         }
     });
 }
@@ -198,22 +227,19 @@ __global__ __launch_bounds__(THREADS) void enc_hist_kernel(EncodeJob *__restrict
         uint64_t above = ~0ull;
         for (uint64_t t = t0; t < t1; ++t) {
             const uint64_t v0 = (t - a_first) * TILE;
+            int64_t x[2 * PAIRS];
+            load_tile(job, v0, n, 0, x);
 #pragma unroll
-            for (int it = 0; it < TILE / (THREADS * 2); ++it) {
-                const uint64_t i = v0 + it * THREADS * 2 + threadIdx.x * 2;
+            for (int e = 0; e < 2 * PAIRS; ++e) {
+                const uint64_t i = v0 + (e >> 1) * THREADS * 2 + threadIdx.x * 2 + (e & 1);
                 if (i < n) {
-                    int64_t x[2];
-                    load_pair(job, i, n, 0, x[0], x[1]);
-                    const int cnt = i + 1 < n ? 2 : 1;
-                    for (int e = 0; e < cnt; e++) {
-                        const uint64_t key = ((uint64_t)x[e] ^ SIGN) - vmin_b;
-                        if (pass == 0) {
-                            atomicAdd(&lh[(uint32_t)(key >> shift)], 1u);
-                        } else {
-                            const uint64_t high = key >> (shift + DIGIT_BITS);
-                            if (high == prefix) atomicAdd(&lh[(uint32_t)(key >> shift) & (BINS - 1)], 1u);
-                            else if (last && high > prefix) above = min(above, key);
-                        }
+                    const uint64_t key = ((uint64_t)x[e] ^ SIGN) - vmin_b;
+                    if (pass == 0) {
+                        atomicAdd(&lh[(uint32_t)(key >> shift)], 1u);
+                    } else {
+                        const uint64_t high = key >> (shift + DIGIT_BITS);
+                        if (high == prefix) atomicAdd(&lh[(uint32_t)(key >> shift) & (BINS - 1)], 1u);
+                        else if (last && high > prefix) above = min(above, key);
                     }
                 }
             }
@@ -319,15 +345,10 @@ __global__ __launch_bounds__(THREADS) void enc_or_kernel(EncodeJob *__restrict__
         uint64_t acc = 0;
         for (uint64_t t = t0; t < t1; ++t) {
             const uint64_t v0 = (t - a_first) * TILE;
+            int64_t x[2 * PAIRS];
+            load_tile(job, v0, n, (int64_t)mid, x);  // fill = mid -> contributes 0 (mid = 0 when plain)
 #pragma unroll
-            for (int it = 0; it < TILE / (THREADS * 2); ++it) {
-                const uint64_t i = v0 + it * THREADS * 2 + threadIdx.x * 2;
-                if (i < n) {
-                    int64_t x0, x1;
-                    load_pair(job, i, n, (int64_t)mid, x0, x1);  // fill = mid -> contributes 0 (mid = 0 when plain)
-                    acc |= to_stream(job, x0, mid) | to_stream(job, x1, mid);
-                }
-            }
+            for (int e = 0; e < 2 * PAIRS; ++e) acc |= to_stream(job, x[e], mid);
         }
         acc = wave_or_u64(acc);
         if ((threadIdx.x & 63) == 0 && acc) atomicOr((unsigned long long *)&jobs[a].or_bits, (unsigned long long)acc);
@@ -386,15 +407,16 @@ __device__ __forceinline__ void pack_tile_packed(const EncodeJob &job, uint64_t 
     const uint32_t w = job.width;
     const uint64_t mid = (uint64_t)job.midpoint;
     // stage zig-zag values (all below 2^31 because w <= 31)
+    {
+        int64_t x[2 * PAIRS];
+        load_tile(job, v0, v0 + nv, (int64_t)mid, x);
 #pragma unroll
-    for (int it = 0; it < TILE / (THREADS * 2); ++it) {
-        const uint32_t j = it * THREADS * 2 + tid * 2;
-        int64_t x0, x1;
-        load_pair(job, v0 + j, v0 + nv, (int64_t)mid, x0, x1);
-        uint2 z;
-        z.x = (uint32_t)to_stream(job, x0, mid);
-        z.y = (uint32_t)to_stream(job, x1, mid);
-        *(uint2 *)(zz + j) = z;
+        for (int it = 0; it < PAIRS; ++it) {
+            uint2 z;
+            z.x = (uint32_t)to_stream(job, x[2 * it], mid);
+            z.y = (uint32_t)to_stream(job, x[2 * it + 1], mid);
+            *(uint2 *)(zz + it * THREADS * 2 + tid * 2) = z;
+        }
     }
     __syncthreads();
     const uintptr_t G = (uintptr_t)job.out + 13 + ((v0 * w) >> 3);
