@@ -35,6 +35,20 @@ def parse_args():
     return ap.parse_args()
 
 
+def pmc_traffic(rows_log2: int):
+    """HBM bytes per decode launch from the PMC counters.  rocprofv3 cannot run inside the timed
+    process, so the figure comes from profiles/: separate --pmc FETCH_SIZE / --pmc WRITE_SIZE
+    passes over this same command (with the gfx950 FETCH_SIZE x2 correction applied there)."""
+    if rows_log2 != 28:
+        return None
+    try:
+        names = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_pmc_traffic.json"))
+        with open(os.path.join(ROOT, "profiles", names[-1])) as f:
+            return int(json.load(f)["hbm_bytes_per_launch"]["total"])
+    except Exception:
+        return None
+
+
 def cpu_baseline(n_sample: int, budget_s: float):
     """The C restatement of the reference codec (oracle/, kind 'port'), one core, decoding the
     first n_sample rows of the same column.  Test infrastructure used as a reported baseline."""
@@ -76,16 +90,24 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: zbra_amd has no CPU path")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # one rank per GPU; ZBRA_BENCH_BACKEND=gloo lets several ranks rehearse on one GPU (the
+    # collective then runs on CPU tensors), the default nccl (= RCCL) needs a GPU per rank
+    backend = os.environ.get("ZBRA_BENCH_BACKEND", "nccl")
+    gpu = local_rank if backend == "nccl" else local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(gpu)
+    dev = torch.device("cuda", gpu)
     if world > 1:
-        dist.init_process_group(backend="nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend=backend)
+    red_dev = dev if backend == "nccl" else "cpu"
 
-    from zbra_amd import device, workloads
+    from zbra_amd import device, sharding, workloads
 
     n = 1 << args.rows_log2
     # -- setup (untimed): generate on device, encode on device ------------------------------
-    values = workloads.narrow_column(SEED, rank * n, n, dev)
+    values = workloads.narrow_column(SEED, sharding.first_row(rank, n), n, dev)
     cap = device.encode_bound(n)
     enc_buf = torch.empty(cap, dtype=torch.uint8, device=dev)
     res = device.new_results(1, dev)
@@ -125,10 +147,8 @@ def main():
     elapsed = time.perf_counter() - t0
     kernel_ms = ev0.elapsed_time(ev1) / args.steps  # per decode launch (plan + tile kernel)
 
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    # whole job: slowest rank's time, every rank's decoded bytes
+    elapsed, decoded_bytes = sharding.job_totals(elapsed, 8.0 * n * args.steps, red_dev)
 
     # -- encode timing (secondary; same config names encode + decode) -------------------------
     encode = None
@@ -151,7 +171,6 @@ def main():
         del enc_buf
 
     if rank == 0:
-        decoded_bytes = 8.0 * n * world * args.steps
         value = decoded_bytes / elapsed / 1e9
         algo_bytes = enc_len + 8.0 * n  # per launch: encoded bytes read + int64 written
         achieved = algo_bytes / (kernel_ms * 1e-3) / 1e9
@@ -172,7 +191,7 @@ def main():
                                    "bit width 12, decode of device-resident bytes",
                        "rows_per_gpu": n, "bit_width": 12, "encoded_bytes": enc_len, "partitioning": f"columns x{world}, no collectives"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None,
+                         "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": pmc_traffic(args.rows_log2),
                          "kernel": "decode_tiles_kernel", "kernel_ms": round(kernel_ms, 4),
                          "algorithmic_bytes_per_launch": int(algo_bytes)},
         }
