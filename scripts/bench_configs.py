@@ -1,0 +1,99 @@
+#!/usr/bin/env python3
+"""Decode rates of the other device-resident configurations on ONE GPU (parity cases, not bench
+lines): 3 = mixed per-array widths, 1e9 rows in 2^20-row arrays; 4 = one GPU's share of the
+sum-typed table (2^29 rows as Blocks of 2^22: enum tags + two Int columns per variant).
+Everything is generated, encoded (batched) and decoded (batched) on the device; the check is the
+exact round trip.  Prints one JSON line per configuration."""
+import argparse
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def timed(fn, reps):
+    import torch
+    fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps
+
+
+def run_batch(cols, label, reps):
+    """cols: list of int64 / int32 tensors.  Batched encode, batched decode, round trip."""
+    import torch
+
+    from zbra_amd import _lib, device
+    dev = cols[0].device
+    kinds = [_lib.ELEM_U32 if c.dtype == torch.int32 else _lib.ELEM_I64 for c in cols]
+    caps = [device.encode_bound(c.numel()) for c in cols]
+    offs, total = [], 0
+    for cap in caps:
+        offs.append(total)
+        total += (cap + 63) // 64 * 64 + 3  # odd offsets, as in a file image
+    enc = torch.empty(total + 64, dtype=torch.uint8, device=dev)
+    res = device.new_results(len(cols), dev)
+    edesc = device.make_encode_descs([(c.data_ptr(), c.numel(), enc.data_ptr() + o, cap, k)
+                                      for c, o, cap, k in zip(cols, offs, caps, kinds)])
+    enc_ms = timed(lambda: device.encode_batch_dev(edesc, res), max(1, reps // 4))
+    rs = device.read_results(res)
+    assert all(r.status == 0 for r in rs)
+    lens = [int(r.out_count) for r in rs]
+    outs = [torch.empty_like(c) for c in cols]
+    ddesc = device.make_descs([(enc.data_ptr() + o, ln, c.numel(), out.data_ptr(), k)
+                               for c, o, ln, out, k in zip(cols, offs, lens, outs, kinds)])
+    dres = device.new_results(len(cols), dev)
+    dec_ms = timed(lambda: device.decode_batch_dev(ddesc, dres), reps)
+    assert all(r.status == 0 and r.out_count == c.numel() for r, c in zip(device.read_results(dres), cols))
+    for c, o in zip(cols, outs):
+        assert torch.equal(c, o), "round trip"
+    rows = sum(c.numel() for c in cols)
+    out_bytes = sum(c.numel() * c.element_size() for c in cols)
+    enc_bytes = sum(lens)
+    widths = sorted(set(r.width for r in rs))
+    return {"case": label, "arrays": len(cols), "rows": rows, "encoded_bytes": enc_bytes, "decoded_bytes": out_bytes,
+            "widths": widths, "decode_ms": round(dec_ms, 4), "decoded_GBps": round(out_bytes / dec_ms / 1e6, 1),
+            "algorithmic_GBps": round((enc_bytes + out_bytes) / dec_ms / 1e6, 1),
+            "hbm_frac": round((enc_bytes + out_bytes) / dec_ms / 1e6 / 8000.0, 4),
+            "encode_ms": round(enc_ms, 4), "encode_GBps_in": round(out_bytes / enc_ms / 1e6, 1)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--config", type=int, nargs="+", default=[3, 4])
+    ap.add_argument("--scale-log2", type=int, default=0, help="divide the row counts by 2^this (smoke runs)")
+    ap.add_argument("--reps", type=int, default=10)
+    args = ap.parse_args()
+    import torch
+
+    from zbra_amd import workloads
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    if 3 in args.config:
+        n = 1_000_000_000 >> args.scale_log2
+        cols = workloads.mixed_width_column(n, 1 << 20, dev)
+        print(json.dumps(run_batch(cols, "config 3: mixed widths, %d rows in 2^20-row arrays" % n, args.reps)), flush=True)
+        del cols
+        torch.cuda.empty_cache()
+    if 4 in args.config:
+        blocks = max(1, 128 >> args.scale_log2)
+        tags, ints = [], []
+        for b in range(blocks):
+            t, variants = workloads.enum_block(b, 1 << 22, dev)
+            tags.append(t)
+            for _, a, bcol in variants:
+                ints += [a, bcol]
+        print(json.dumps(run_batch(tags, "config 4 (one GPU's 2^29 rows): enum tags -> u32, %d Blocks" % blocks, args.reps)), flush=True)
+        print(json.dumps(run_batch(ints, "config 4: Int columns of the variants, %d arrays" % len(ints), args.reps)), flush=True)
+        print(json.dumps(run_batch(tags + ints, "config 4: tags + Int columns in one submission", args.reps)), flush=True)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,94 @@
+"""GPU parity on the shapes of the other benchmark configurations, at sizes the oracle finishes in
+seconds: mixed per-array widths with the adversarial arrays (config 3) and the sum-typed table's
+Blocks — enum tags as u32 plus two Int columns per variant with ragged lengths (config 4).  The
+device generators are checked against numpy restatements of the same formulas first."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def env():
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need a device"
+    from oracle import zbra_oracle_c as oc
+    from oracle import zbra_oracle_np as on
+    from zbra_amd import _lib, device, workloads
+    return torch, device, workloads, oc, on, _lib
+
+
+def _np_mixed_chunk(on, c, first, n):
+    base = int(on.sm(0x5EED0003, np.array([c], dtype=np.uint64))[0])
+    base = ((base & ((1 << 48) - 1)) ^ (1 << 47)) - (1 << 47)
+    a = 1 + int(on.sm(0x5EED1003, np.array([c], dtype=np.uint64))[0] % np.uint64(40))
+    idx = np.arange(first, first + n, dtype=np.uint64)
+    r = (on.sm(0x5EED2003, idx) & np.uint64((1 << a) - 1)).astype(np.int64)
+    return r - (1 << (a - 1)) + base
+
+
+def test_generators_match_numpy(env):
+    torch, device, workloads, oc, on, L = env
+    dev = torch.device("cuda", 0)
+    v = workloads.narrow_column(0x5EED0002, 12345, 5000, dev).cpu().numpy()
+    assert np.array_equal(v, oc.gen_narrow(0x5EED0002, 12345, 5000))
+    for c in (5, 6, 17, 40):
+        t = workloads.mixed_width_chunk(c, 1000 * c, 3000, dev).cpu().numpy()
+        assert np.array_equal(t, _np_mixed_chunk(on, c, 1000 * c, 3000)), c
+    tags, variants = workloads.enum_block(3, 4096, dev)
+    r = np.arange(3 * 4096, 4 * 4096, dtype=np.uint64)
+    u = (on.sm(0x5EED0004, r) % np.uint64(100)).astype(np.int64)
+    expect = np.where(u < 50, 0, np.where(u < 75, 1, np.where(u < 90, 2, 7))).astype(np.int32)
+    assert np.array_equal(tags.cpu().numpy(), expect)
+    assert sum(a.numel() for _, a, _ in variants) == 4096
+
+
+def _batch_roundtrip_vs_oracle(env, cols):
+    torch, device, workloads, oc, on, L = env
+    dev = cols[0].device
+    kinds = [L.ELEM_U32 if c.dtype == torch.int32 else L.ELEM_I64 for c in cols]
+    caps = [device.encode_bound(c.numel()) for c in cols]
+    offs, total = [], 0
+    for cap in caps:
+        offs.append(total)
+        total += cap + 5
+    enc = torch.zeros(total + 64, dtype=torch.uint8, device=dev)
+    res = device.new_results(len(cols), dev)
+    device.encode_batch_dev(device.make_encode_descs(
+        [(c.data_ptr(), c.numel(), enc.data_ptr() + o, cap, k) for c, o, cap, k in zip(cols, offs, caps, kinds)]), res)
+    rs = device.read_results(res)
+    enc_h = enc.cpu().numpy()
+    lens = []
+    for i, c in enumerate(cols):
+        h = c.cpu().numpy()
+        expect = oc.compress_int_array(h.view(np.uint32).astype(np.int64) if c.dtype == torch.int32 else h)
+        assert rs[i].status == 0 and rs[i].out_count == len(expect), i
+        assert enc_h[offs[i]:offs[i] + len(expect)].tobytes() == expect, i
+        lens.append(len(expect))
+    outs = [torch.full_like(c, -9) for c in cols]
+    dres = device.new_results(len(cols), dev)
+    device.decode_batch_dev(device.make_descs(
+        [(enc.data_ptr() + o, ln, c.numel(), out.data_ptr(), k) for c, o, ln, out, k in zip(cols, offs, lens, outs, kinds)]), dres)
+    for i, (c, o) in enumerate(zip(cols, outs)):
+        assert torch.equal(c, o), i
+    return sorted(set(r.width for r in rs))
+
+
+def test_config3_mixed_widths_reduced(env):
+    torch, device, workloads, oc, on, L = env
+    cols = workloads.mixed_width_column(60 * 4096 + 1234, 4096, torch.device("cuda", 0))
+    assert cols[0].numel() == 4096 and cols[3].numel() == 1 and cols[4].numel() == 4095
+    widths = _batch_roundtrip_vs_oracle(env, cols)
+    assert 1 in widths and 64 in widths and len(widths) > 20  # constant / MIN-MAX -> 1, full range -> 64
+
+
+def test_config4_enum_blocks_reduced(env):
+    torch, device, workloads, oc, on, L = env
+    cols = []
+    for b in range(3):
+        tags, variants = workloads.enum_block(b, 1 << 15, torch.device("cuda", 0))
+        cols.append(tags)
+        for _, a, bcol in variants:
+            cols += [a, bcol]
+    widths = _batch_roundtrip_vs_oracle(env, cols)
+    assert 4 in widths  # tags {0,1,2,7} around the median

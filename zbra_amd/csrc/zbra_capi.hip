@@ -103,8 +103,9 @@ static const DecodeConfig &decode_config() {
     }();
     return cfg;
 }
-static inline uint64_t decode_tiles_of(uint64_t count) {
-    const uint64_t t = (uint64_t)decode_config().tile;
+// Tiles of one array: u32 outputs use tiles of twice the values (see decode_tiles_kernel).
+static inline uint64_t decode_tiles_of(uint64_t count, uint32_t kind) {
+    const uint64_t t = (uint64_t)decode_config().tile * (kind == ZBRA_ELEM_U32 ? 2 : 1);
     return (count + t - 1) / t;
 }
 static void launch_decode(hipStream_t stream, const DecodePlan *plans, const uint64_t *ts, uint32_t nd, uint64_t ntiles) {
@@ -136,7 +137,7 @@ static int decode_batch_dev(DeviceCtx *ctx, const zbra_array_desc *descs, size_t
         if ((d.len && !d.data) || (d.count && d.len && !d.out)) return ZBRA_ERR_INVALID_ARG;
     }
     if (nd == 1) {
-        const uint64_t ntiles = decode_tiles_of(descs[0].count);
+        const uint64_t ntiles = decode_tiles_of(descs[0].count, descs[0].kind);
         Slot *s;
         ZBRA_TRY(ctx->acquire(256, &s));
         DecodePlan *plan = (DecodePlan *)s->dev;
@@ -156,7 +157,7 @@ static int decode_batch_dev(DeviceCtx *ctx, const zbra_array_desc *descs, size_t
     std::memcpy(s->host, descs, nd * sizeof(zbra_array_desc));
     uint64_t *h_ts = (uint64_t *)((char *)s->host + off_ts);
     uint64_t run = 0;
-    for (size_t i = 0; i < nd; i++) { h_ts[i] = run; run += decode_tiles_of(descs[i].count); }
+    for (size_t i = 0; i < nd; i++) { h_ts[i] = run; run += decode_tiles_of(descs[i].count, descs[i].kind); }
     h_ts[nd] = run;
     const uint64_t ntiles = run;
     int st = hip_status(hipMemcpyAsync(s->dev, s->host, off_ts + (nd + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, stream));
@@ -478,7 +479,7 @@ int zbra_hip_bp64_unpack(const uint8_t *packed, size_t packed_len, size_t count,
     ZBRA_TRY(DeviceCtx::grow_dev(ctx->dev_out, count * 8));
     ZBRA_HIP_TRY(hipMemcpyAsync(ctx->dev_in.ptr, packed, packed_len, hipMemcpyHostToDevice, ctx->stream));
     ZBRA_TRY(DeviceCtx::grow_dev(ctx->dev_tmp, 256));
-    const uint64_t ntiles = decode_tiles_of(count);
+    const uint64_t ntiles = decode_tiles_of(count, KIND_U64_PLAIN);
     DecodePlan *plan = (DecodePlan *)ctx->dev_tmp.ptr;
     uint64_t *tile_start = (uint64_t *)((char *)ctx->dev_tmp.ptr + 64);
     hipLaunchKernelGGL(plan_unpack_kernel, dim3(1), dim3(64), 0, ctx->stream, (const uint8_t *)ctx->dev_in.ptr,

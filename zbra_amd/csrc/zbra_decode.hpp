@@ -309,23 +309,28 @@ template <int DT, int TH, bool NT, bool DIRECT>
 __global__ __launch_bounds__(TH) void decode_tiles_kernel(const DecodePlan *__restrict__ plans,
                                                           const uint64_t *__restrict__ tile_start, uint32_t nd,
                                                           uint64_t ntiles, uint32_t xcd_chunked) {
-    __shared__ __attribute__((aligned(16))) uint32_t lds[lds_dwords<DT>()];
+    // u32 outputs are half as wide, so their tiles hold twice the values (same bytes written)
+    __shared__ __attribute__((aligned(16))) uint32_t lds[lds_dwords<2 * DT>()];
     // xcd_chunked implies gridDim.x == ntiles: exactly one trip through the loop
     uint64_t t = xcd_chunked ? xcd_chunked_tile(blockIdx.x, ntiles) : blockIdx.x;
     for (; t < ntiles; t += gridDim.x) {
         const uint32_t a = nd > 1 ? find_array(tile_start, nd, t) : 0;
         const DecodePlan p = plans[a];
-        const uint64_t v0 = (t - tile_start[a]) * DT;
+        const bool narrow = p.kind == ZBRA_ELEM_U32;
+        const uint32_t tv = narrow ? 2 * DT : DT;
+        const uint64_t v0 = (t - tile_start[a]) * tv;
         if (v0 >= p.count) continue;  // rejected or empty array: its tiles do nothing
         const uint64_t left = p.count - v0;
-        const uint32_t nv = left < (uint64_t)DT ? (uint32_t)left : (uint32_t)DT;
+        const uint32_t nv = left < (uint64_t)tv ? (uint32_t)left : tv;
         if (p.width - 1u < 31u) {
-            if (DIRECT && p.kind != ZBRA_ELEM_U32) tile_packed_direct<DT, TH, NT>(p, v0, nv);
+            if (narrow) tile_packed<2 * DT, TH, NT>(p, v0, nv, lds);
+            else if (DIRECT) tile_packed_direct<DT, TH, NT>(p, v0, nv);
             else tile_packed<DT, TH, NT>(p, v0, nv, lds);
         } else if (p.width == 0) {
             tile_fill<TH>(p, v0, nv);
         } else {
-            tile_raw<DT, TH, NT>(p, v0, nv);
+            if (narrow) tile_raw<2 * DT, TH, NT>(p, v0, nv);
+            else tile_raw<DT, TH, NT>(p, v0, nv);
         }
     }
 }

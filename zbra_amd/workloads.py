@@ -58,3 +58,59 @@ def mixed_width_chunk(c: int, first: int, n: int, device) -> torch.Tensor:
     idx = torch.arange(first, first + n, dtype=torch.int64, device=device)
     r = sm(0x5EED2003, idx) & ((1 << a) - 1)
     return r - (1 << (a - 1)) + base
+
+
+I64_MIN, I64_MAX = -(1 << 63), (1 << 63) - 1
+
+
+def mixed_width_column(n_total: int, chunk_rows: int, device):
+    """Mixed-width stress column: n_total rows cut into arrays of chunk_rows rows (the last one
+    shorter).  Chunk c >= 5 is mixed_width_chunk(c, ...); chunks 0..4 are adversarial:
+    0 constant, 1 alternating i64::MIN / i64::MAX, 2 full-range random (width 64), 3 a single
+    value, 4 an odd length (chunk_rows - 1).  Returns a list of int64 tensors."""
+    out = []
+    first, c = 0, 0
+    while first < n_total:
+        n = min(chunk_rows, n_total - first)
+        if c == 0:
+            t = torch.full((n,), -987654321012345, dtype=torch.int64, device=device)
+        elif c == 1:
+            t = torch.where(torch.arange(n, device=device) % 2 == 0, torch.tensor(I64_MIN, device=device),
+                            torch.tensor(I64_MAX, device=device))
+        elif c == 2:
+            t = sm(0x5EED2003, torch.arange(first, first + n, dtype=torch.int64, device=device))
+        elif c == 3:
+            n = 1
+            t = torch.tensor([424242], dtype=torch.int64, device=device)
+        elif c == 4:
+            n = min(n, chunk_rows - 1)
+            t = mixed_width_chunk(c, first, n, device)
+        else:
+            t = mixed_width_chunk(c, first, n, device)
+        out.append(t)
+        first += n
+        c += 1
+    return out
+
+
+_CLUSTERS = (100, 1000, 10000, 100000)
+
+
+def enum_block(block: int, rows: int, device):
+    """One Block of the sum-typed table: Enum.tags over {0,1,2,7} with probabilities
+    50/25/15/10 % (row r of the table draws sm(0x5EED0004, r) mod 100), and per variant a struct
+    of two Int columns whose length is that variant's row count: A clustered
+    (benches/compression.rs:25-34 pattern), B time series with 1 s steps (:36-40 pattern).
+    Returns (tags:int32 tensor, [(tag, colA, colB), ...])."""
+    r = torch.arange(block * rows, (block + 1) * rows, dtype=torch.int64, device=device)
+    u = umod(sm(0x5EED0004, r), 100)
+    tags = torch.where(u < 50, 0, torch.where(u < 75, 1, torch.where(u < 90, 2, 7))).to(torch.int32)
+    variants = []
+    clusters = torch.tensor(_CLUSTERS, dtype=torch.int64, device=device)
+    for tag in (0, 1, 2, 7):
+        cnt = int((tags == tag).sum().item())
+        i = torch.arange(cnt, dtype=torch.int64, device=device)
+        col_a = clusters[i % 4] + (i % 20) - 10
+        col_b = 1640995200000 + (block * rows + i) * 1000
+        variants.append((tag, col_a, col_b))
+    return tags, variants
