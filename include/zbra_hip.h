@@ -49,6 +49,10 @@ typedef enum zbra_status {
     ZBRA_ERR_CAPACITY = 4,    /* caller's output buffer is too small */
     ZBRA_ERR_INVALID_ARG = 5, /* NULL pointer with a non-zero size, count above 2^32-1, ... */
     ZBRA_ERR_NO_DEVICE = 6,   /* no HIP device / HIP runtime unusable */
+    /* .zbra image: BinaryError::InvalidMagicNumber / Invalid{Table,Column,Default,Encoding,
+     * IntEncoding,BinaryEncoding}Tag / unexpected end of data   binary.rs:143-145, 268, 439, 500,
+     * 526, 551, 570 */
+    ZBRA_ERR_FORMAT = 7,
     ZBRA_ERR_HIP_BASE = 100   /* status - 100 = hipError_t */
 } zbra_status;
 
@@ -88,6 +92,40 @@ typedef struct zbra_encode_desc {
     uint32_t kind;      /* zbra_elem_kind */
     uint32_t reserved;
 } zbra_encode_desc;
+
+/* Which striped vector an int array of a .zbra image carries (the six call sites of
+ * binary.rs:366-434). */
+typedef enum zbra_array_role {
+    ZBRA_ROLE_INT_VALUES = 0,     /* Column::Int.values                 binary.rs:369 */
+    ZBRA_ROLE_DOUBLE_BITS = 1,    /* Column::Double.values as i64 bits  binary.rs:378-382 */
+    ZBRA_ROLE_BINARY_LENGTHS = 2, /* Column::Binary.lengths             binary.rs:388 */
+    ZBRA_ROLE_ARRAY_LENGTHS = 3,  /* Column::Array.lengths              binary.rs:399 */
+    ZBRA_ROLE_ENUM_TAGS = 4,      /* Column::Enum.tags (u32)            binary.rs:418 */
+    ZBRA_ROLE_NESTED_LENGTHS = 5  /* Column::Nested.lengths             binary.rs:431 */
+} zbra_array_role;
+
+/* One int array found in a .zbra image by zbra_hip_file_index, in file order. */
+typedef struct zbra_file_array {
+    uint64_t offset; /* of E (the byte after `u32 count | u32 clen`) in the image */
+    uint64_t len;    /* clen */
+    uint64_t count;  /* count from the frame */
+    uint32_t kind;   /* zbra_elem_kind the reader narrows to: U32 for enum tags, else I64 */
+    uint32_t role;   /* zbra_array_role */
+    uint32_t block;  /* index of the Block it belongs to */
+    uint32_t reserved;
+} zbra_file_array;
+
+/* Summary of a .zbra image. */
+typedef struct zbra_file_info {
+    uint64_t schema_offset, schema_len;           /* JSON TableSchema, stored as is  binary.rs:108-113 */
+    uint64_t compression_offset, compression_len; /* JSON CompressionConfig          binary.rs:116-121 */
+    uint64_t blocks_offset;                       /* of the u32 block_count          binary.rs:124 */
+    uint32_t block_count;
+    uint32_t reserved;
+    uint64_t n_arrays;                            /* int arrays in all Blocks */
+    uint64_t total_values;                        /* sum of their counts */
+    uint64_t end_offset;                          /* first byte after the last Block */
+} zbra_file_info;
 
 /* ---- library / device ------------------------------------------------------------------- */
 
@@ -147,6 +185,25 @@ int zbra_hip_decode_batch_dev(const zbra_array_desc *descs, size_t nd, zbra_dev_
  * NULL).                                                             compression.rs:271-292 */
 int zbra_hip_encode_dev(const void *d_values, size_t n, uint32_t kind, uint8_t *d_out, size_t cap,
                         zbra_dev_result *d_result, void *stream);
+
+/* ---- .zbra images ------------------------------------------------------------------------ */
+
+/* Walks a .zbra image the way BinaryFile::read_from does (binary.rs:139-174, 195-199, 240-270,
+ * 359-441) without decoding anything: every int array is length-prefixed and byte blobs are
+ * skipped by their compressed size (binary.rs:694-697).  Pure host code, no device needed.
+ * Writes up to `cap` entries to `arrays` (may be NULL with cap 0 to count only); info->n_arrays
+ * is the number found.  ZBRA_ERR_FORMAT: bad magic, invalid tag or truncated image (*err_offset,
+ * if not NULL, gets the offset where the walk stopped). */
+int zbra_hip_file_index(const uint8_t *image, size_t len, zbra_file_array *arrays, size_t cap, zbra_file_info *info,
+                        size_t *err_offset);
+
+/* Decodes int arrays of a .zbra image that is in HOST memory into HOST buffers: the whole-file
+ * read path.  arrays[i] (from zbra_hip_file_index) goes to outs[i], which holds arrays[i].count
+ * elements of arrays[i].kind.  Copies (pinned hipMemcpyAsync) and kernels of neighbouring groups
+ * of arrays overlap.  statuses (may be NULL) receives one zbra_status per array; the return value
+ * is the first non-OK status. */
+int zbra_hip_file_decode(const uint8_t *image, size_t len, const zbra_file_array *arrays, size_t n, void *const *outs,
+                         int *statuses);
 
 /* The same for `nd` independent arrays in one submission (Column::write_to encodes the arrays of
  * a Block one after another, binary.rs:275-356).  `descs` is a HOST array of DEVICE pointers;

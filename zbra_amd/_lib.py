@@ -28,6 +28,20 @@ class EncodeDesc(C.Structure):
                 ("kind", C.c_uint32), ("reserved", C.c_uint32)]
 
 
+class FileArray(C.Structure):
+    """zbra_file_array of include/zbra_hip.h."""
+    _fields_ = [("offset", C.c_uint64), ("len", C.c_uint64), ("count", C.c_uint64), ("kind", C.c_uint32),
+                ("role", C.c_uint32), ("block", C.c_uint32), ("reserved", C.c_uint32)]
+
+
+class FileInfo(C.Structure):
+    """zbra_file_info of include/zbra_hip.h."""
+    _fields_ = [("schema_offset", C.c_uint64), ("schema_len", C.c_uint64), ("compression_offset", C.c_uint64),
+                ("compression_len", C.c_uint64), ("blocks_offset", C.c_uint64), ("block_count", C.c_uint32),
+                ("reserved", C.c_uint32), ("n_arrays", C.c_uint64), ("total_values", C.c_uint64),
+                ("end_offset", C.c_uint64)]
+
+
 _p, _sz = C.c_void_p, C.c_size_t
 _psz = C.POINTER(C.c_size_t)
 
@@ -53,6 +67,8 @@ SIGNATURES = {
     "zbra_hip_decode_batch_dev": (C.c_int, [C.POINTER(ArrayDesc), _sz, _p, _p]),
     "zbra_hip_encode_dev": (C.c_int, [_p, _sz, C.c_uint32, _p, _sz, _p, _p]),
     "zbra_hip_encode_batch_dev": (C.c_int, [C.POINTER(EncodeDesc), _sz, _p, _p]),
+    "zbra_hip_file_index": (C.c_int, [_p, _sz, C.POINTER(FileArray), _sz, C.POINTER(FileInfo), _psz]),
+    "zbra_hip_file_decode": (C.c_int, [_p, _sz, C.POINTER(FileArray), _sz, C.POINTER(C.c_void_p), C.POINTER(C.c_int)]),
 }
 
 
@@ -85,6 +101,7 @@ ERR_TRUNCATED = 3
 ERR_CAPACITY = 4
 ERR_INVALID_ARG = 5
 ERR_NO_DEVICE = 6
+ERR_FORMAT = 7
 ERR_HIP_BASE = 100
 ELEM_I64 = 0
 ELEM_U32 = 1

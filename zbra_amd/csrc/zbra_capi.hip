@@ -13,6 +13,7 @@
 #include "zbra_decode.hpp"
 #include "zbra_encode.hpp"
 #include "zbra_stages.hpp"
+#include "zbra_file.hpp"
 
 namespace zbra {
 
@@ -349,6 +350,7 @@ const char *zbra_hip_strerror(int status) {
         case ZBRA_ERR_CAPACITY: return "Output buffer too small";
         case ZBRA_ERR_INVALID_ARG: return "Invalid argument";
         case ZBRA_ERR_NO_DEVICE: return "No usable HIP device";
+        case ZBRA_ERR_FORMAT: return "Invalid .zbra image (magic number, tag or length)";
         default:
             if (status >= ZBRA_ERR_HIP_BASE) return hipGetErrorString((hipError_t)(status - ZBRA_ERR_HIP_BASE));
             return "unknown status";
@@ -523,6 +525,102 @@ int zbra_hip_encode_batch_dev(const zbra_encode_desc *descs, size_t nd, zbra_dev
     std::vector<EncodeItem> items(nd);
     for (size_t i = 0; i < nd; i++) items[i] = EncodeItem{descs[i].values, descs[i].n, descs[i].kind, descs[i].out, descs[i].cap};
     return encode_batch_dev(ctx, items.data(), nd, d_results, (hipStream_t)stream);
+}
+
+int zbra_hip_file_index(const uint8_t *image, size_t len, zbra_file_array *arrays, size_t cap, zbra_file_info *info,
+                        size_t *err_offset) {
+    if (!info || (len && !image) || (cap && !arrays)) return ZBRA_ERR_INVALID_ARG;
+    std::memset(info, 0, sizeof(*info));
+    std::vector<zbra_file_array> found;
+    Walker w{image, len};
+    if (cap) w.arrays = &found;
+    if (!w.file(info)) {
+        if (err_offset) *err_offset = w.fail_pos;
+        return ZBRA_ERR_FORMAT;
+    }
+    if (cap) {
+        if (found.size() > cap) return ZBRA_ERR_CAPACITY;
+        std::memcpy(arrays, found.data(), found.size() * sizeof(zbra_file_array));
+    }
+    return ZBRA_OK;
+}
+
+int zbra_hip_file_decode(const uint8_t *image, size_t len, const zbra_file_array *arrays, size_t n, void *const *outs,
+                         int *statuses) {
+    if (n == 0) return ZBRA_OK;
+    if (!image || !arrays || !outs) return ZBRA_ERR_INVALID_ARG;
+    for (size_t i = 0; i < n; i++) {
+        if (arrays[i].offset > len || arrays[i].len > len - arrays[i].offset) return ZBRA_ERR_INVALID_ARG;
+        if (arrays[i].count > MAX_COUNT || arrays[i].kind > ZBRA_ELEM_U32) return ZBRA_ERR_INVALID_ARG;
+        if (arrays[i].count && arrays[i].len && !outs[i]) return ZBRA_ERR_INVALID_ARG;
+        if (i && arrays[i].offset < arrays[i - 1].offset + arrays[i - 1].len) return ZBRA_ERR_INVALID_ARG;  // file order
+    }
+    DeviceCtx *ctx;
+    ZBRA_TRY(current_ctx(&ctx));
+    std::lock_guard<std::mutex> g(ctx->host_mu);
+    ZBRA_TRY(ctx->ensure_file_lanes());
+    // Groups of consecutive arrays: bounded image span and bounded output, so that the copies of
+    // one group overlap the kernels of the next on the other lane.
+    constexpr size_t MAX_SPAN = (size_t)64 << 20, MAX_OUT = (size_t)512 << 20, MAX_ARRAYS = 4096;
+    std::vector<zbra_dev_result> results(n);
+    std::vector<zbra_array_desc> descs;
+    size_t i = 0, lane_idx = 0;
+    int first_err = ZBRA_OK;
+    while (i < n) {
+        size_t j = i, out_bytes = 0;
+        const size_t lo = arrays[i].offset;
+        size_t hi = lo;
+        while (j < n && j - i < MAX_ARRAYS) {
+            const size_t esz = arrays[j].kind == ZBRA_ELEM_I64 ? 8 : 4;
+            const size_t ob = (arrays[j].count * esz + 15) / 16 * 16;
+            const size_t h = arrays[j].offset + arrays[j].len;
+            if (j > i && (h - lo > MAX_SPAN || out_bytes + ob > MAX_OUT)) break;
+            out_bytes += ob;
+            hi = h;
+            j++;
+        }
+        FileLane &lane = ctx->file_lanes[lane_idx];
+        lane_idx ^= 1;
+        // the lane's buffers are reused: everything enqueued on it earlier must have run before
+        // they may be reallocated (same-size reuse is ordered by the stream itself)
+        const size_t span = hi - lo, ng = j - i;
+        if (lane.img.cap < span + 16 || lane.out.cap < out_bytes + 16 || lane.res.cap < ng * sizeof(zbra_dev_result)) {
+            ZBRA_HIP_TRY(hipStreamSynchronize(lane.stream));
+            ZBRA_TRY(DeviceCtx::grow_dev(lane.img, span + 16));
+            ZBRA_TRY(DeviceCtx::grow_dev(lane.out, out_bytes + 16));
+            ZBRA_TRY(DeviceCtx::grow_dev(lane.res, ng * sizeof(zbra_dev_result)));
+        }
+        if (span) ZBRA_HIP_TRY(hipMemcpyAsync(lane.img.ptr, image + lo, span, hipMemcpyHostToDevice, lane.stream));
+        descs.resize(ng);
+        size_t o = 0;
+        for (size_t k = 0; k < ng; k++) {
+            const zbra_file_array &a = arrays[i + k];
+            descs[k].data = (const uint8_t *)lane.img.ptr + (a.offset - lo);
+            descs[k].len = a.len; descs[k].count = a.count; descs[k].out = (char *)lane.out.ptr + o;
+            descs[k].kind = a.kind; descs[k].reserved = 0;
+            o += (a.count * (a.kind == ZBRA_ELEM_I64 ? 8 : 4) + 15) / 16 * 16;
+        }
+        ZBRA_TRY(decode_batch_dev(ctx, descs.data(), ng, (zbra_dev_result *)lane.res.ptr, lane.stream));
+        ZBRA_HIP_TRY(hipMemcpyAsync(&results[i], lane.res.ptr, ng * sizeof(zbra_dev_result), hipMemcpyDeviceToHost, lane.stream));
+        // The number of values an array produces is known from its header, which the host can
+        // read in the image: copy back exactly that (0 for empty / rejected arrays).
+        for (size_t k = 0; k < ng; k++) {
+            const zbra_file_array &a = arrays[i + k];
+            size_t produced = 0;
+            const int st = host_check_decode(image + a.offset, a.len, a.count, &produced);
+            if (st == ZBRA_OK && produced)
+                ZBRA_HIP_TRY(hipMemcpyAsync(outs[i + k], descs[k].out, produced * (a.kind == ZBRA_ELEM_I64 ? 8 : 4),
+                                            hipMemcpyDeviceToHost, lane.stream));
+        }
+        i = j;
+    }
+    ZBRA_HIP_TRY(hipStreamSynchronize(ctx->file_lanes[0].stream));
+    ZBRA_HIP_TRY(hipStreamSynchronize(ctx->file_lanes[1].stream));
+    for (size_t k = 0; k < n; k++) {
+        if (statuses) statuses[k] = (int)results[k].status;
+        if (results[k].status != ZBRA_OK && first_err == ZBRA_OK) first_err = (int)results[k].status;
+    }
+    return first_err;
 }
 
 }  // extern "C"

@@ -41,8 +41,21 @@ struct Arena {
     size_t cap = 0;
 };
 
+// One of the two alternating lanes of the whole-file decode: a stream and the device buffers of
+// the group of arrays in flight on it.
+struct FileLane {
+    hipStream_t stream = nullptr;
+    Arena img, out, res;
+};
+
 struct DeviceCtx {
     int device = -1;
+    FileLane file_lanes[2];
+    int ensure_file_lanes() {
+        for (FileLane &l : file_lanes)
+            if (!l.stream) ZBRA_HIP_TRY(hipStreamCreateWithFlags(&l.stream, hipStreamNonBlocking));
+        return ZBRA_OK;
+    }
     std::mutex mu;              // guards slots
     std::vector<Slot *> slots;  // pointers stay valid while the vector grows
     std::mutex host_mu;         // serialises host-pointer calls: they share the arenas and the stream
