@@ -48,9 +48,9 @@ static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; 
 // ZBRA_HIP_DECODE_VARIANT="tile:threads:nt:direct" and ZBRA_HIP_DECODE_GRID override them
 // (tuning aids).
 struct DecodeConfig {
-    int tile = 1024;
-    int threads = 256;
-    int nt = 1;
+    int tile = 2048;
+    int threads = 512;
+    int nt = 3;  // bit 0: nontemporal loads, bit 1: nontemporal stores
     int direct = 0;
     int xcd = 1;  // XCD-chunked tile order
     unsigned grid_cap = 0x7FFFFFFFu;  // one workgroup per tile
@@ -61,13 +61,19 @@ static void launch_decode_t(const DecodeConfig &c, unsigned grid, hipStream_t st
                             const uint64_t *ts, uint32_t nd, uint64_t ntiles) {
     const dim3 g(grid), b(TH);
     const uint32_t x = (c.xcd && (uint64_t)grid == ntiles && ntiles >= 64) ? 1u : 0u;
-    if (c.nt) {
-        if (c.direct) hipLaunchKernelGGL((decode_tiles_kernel<DT, TH, true, true>), g, b, 0, stream, plans, ts, nd, ntiles, x);
-        else hipLaunchKernelGGL((decode_tiles_kernel<DT, TH, true, false>), g, b, 0, stream, plans, ts, nd, ntiles, x);
-    } else {
-        if (c.direct) hipLaunchKernelGGL((decode_tiles_kernel<DT, TH, false, true>), g, b, 0, stream, plans, ts, nd, ntiles, x);
-        else hipLaunchKernelGGL((decode_tiles_kernel<DT, TH, false, false>), g, b, 0, stream, plans, ts, nd, ntiles, x);
+#define ZBRA_LAUNCH_DECODE(NTV, DIR) \
+    hipLaunchKernelGGL((decode_tiles_kernel<DT, TH, NTV, DIR>), g, b, 0, stream, plans, ts, nd, ntiles, x)
+    switch ((c.nt & 3) * 2 + (c.direct ? 1 : 0)) {
+        case 0: ZBRA_LAUNCH_DECODE(0, false); break;
+        case 1: ZBRA_LAUNCH_DECODE(0, true); break;
+        case 2: ZBRA_LAUNCH_DECODE(1, false); break;
+        case 3: ZBRA_LAUNCH_DECODE(1, true); break;
+        case 4: ZBRA_LAUNCH_DECODE(2, false); break;
+        case 5: ZBRA_LAUNCH_DECODE(2, true); break;
+        case 6: ZBRA_LAUNCH_DECODE(3, false); break;
+        default: ZBRA_LAUNCH_DECODE(3, true); break;
     }
+#undef ZBRA_LAUNCH_DECODE
 }
 
 typedef void (*DecodeLauncher)(const DecodeConfig &, unsigned, hipStream_t, const DecodePlan *, const uint64_t *, uint32_t,
@@ -81,28 +87,33 @@ static const DecodeShape kDecodeShapes[] = {
     {2048, 1024, launch_decode_t<2048, 1024>}, {4096, 1024, launch_decode_t<4096, 1024>},
 };
 
-static DecodeLauncher g_decode_fn = launch_decode_t<1024, 256>;
+static DecodeLauncher g_decode_fn = launch_decode_t<2048, 512>;
+static DecodeConfig g_decode_cfg;
+static bool apply_variant(DecodeConfig &c, int t, int th, int n, int d) {
+    for (const DecodeShape &sh : kDecodeShapes)
+        if (sh.tile == t && sh.threads == th) {
+            c.tile = t; c.threads = th; c.nt = n & 3; c.direct = d != 0;
+            g_decode_fn = sh.fn;
+            return true;
+        }
+    return false;
+}
 static const DecodeConfig &decode_config() {
-    static const DecodeConfig cfg = [] {
-        DecodeConfig c;
+    static const bool once = [] {
+        DecodeConfig &c = g_decode_cfg;
         if (const char *e = getenv("ZBRA_HIP_DECODE_VARIANT")) {
             int t = 0, th = 0, n = 0, d = 0;
-            if (sscanf(e, "%d:%d:%d:%d", &t, &th, &n, &d) == 4) {
-                for (const DecodeShape &sh : kDecodeShapes)
-                    if (sh.tile == t && sh.threads == th) {
-                        c.tile = t; c.threads = th; c.nt = n != 0; c.direct = d != 0;
-                        g_decode_fn = sh.fn;
-                    }
-            }
+            if (sscanf(e, "%d:%d:%d:%d", &t, &th, &n, &d) == 4) apply_variant(c, t, th, n, d);
         }
         if (const char *e = getenv("ZBRA_HIP_DECODE_XCD")) c.xcd = atoi(e) != 0;
         if (const char *e = getenv("ZBRA_HIP_DECODE_GRID")) {
             const long v = atol(e);
             if (v > 0) c.grid_cap = (unsigned)v;
         }
-        return c;
+        return true;
     }();
-    return cfg;
+    (void)once;
+    return g_decode_cfg;
 }
 // Tiles of one array: u32 outputs use tiles of twice the values (see decode_tiles_kernel).
 static inline uint64_t decode_tiles_of(uint64_t count, uint32_t kind) {
@@ -338,6 +349,14 @@ static int stage_host(const void *in, size_t in_bytes, void *out, size_t out_byt
 using namespace zbra;
 
 extern "C" {
+
+// Tuning hook (not part of the ABI, not declared in the header): switches the decode kernel shape
+// at run time so that variants can be timed interleaved in one process.  Not thread-safe.
+int zbra_tuning_set_decode_variant(int tile, int threads, int nt, int direct, int xcd) {
+    (void)decode_config();
+    g_decode_cfg.xcd = xcd;
+    return apply_variant(g_decode_cfg, tile, threads, nt, direct) ? 0 : 1;
+}
 
 const char *zbra_hip_version(void) { return "zbra-hip 0.1 (gfx950)"; }
 
