@@ -58,11 +58,11 @@ struct DecodeConfig {
 
 template <int DT, int TH>
 static void launch_decode_t(const DecodeConfig &c, unsigned grid, hipStream_t stream, const DecodePlan *plans,
-                            const uint64_t *ts, uint32_t nd, uint64_t ntiles) {
+                            const uint64_t *ts, const uint32_t *tmap, uint32_t nd, uint64_t ntiles) {
     const dim3 g(grid), b(TH);
     const uint32_t x = (c.xcd && (uint64_t)grid == ntiles && ntiles >= 64) ? 1u : 0u;
 #define ZBRA_LAUNCH_DECODE(NTV, DIR) \
-    hipLaunchKernelGGL((decode_tiles_kernel<DT, TH, NTV, DIR>), g, b, 0, stream, plans, ts, nd, ntiles, x)
+    hipLaunchKernelGGL((decode_tiles_kernel<DT, TH, NTV, DIR>), g, b, 0, stream, plans, ts, tmap, nd, ntiles, x)
     switch ((c.nt & 3) * 2 + (c.direct ? 1 : 0)) {
         case 0: ZBRA_LAUNCH_DECODE(0, false); break;
         case 1: ZBRA_LAUNCH_DECODE(0, true); break;
@@ -76,8 +76,8 @@ static void launch_decode_t(const DecodeConfig &c, unsigned grid, hipStream_t st
 #undef ZBRA_LAUNCH_DECODE
 }
 
-typedef void (*DecodeLauncher)(const DecodeConfig &, unsigned, hipStream_t, const DecodePlan *, const uint64_t *, uint32_t,
-                               uint64_t);
+typedef void (*DecodeLauncher)(const DecodeConfig &, unsigned, hipStream_t, const DecodePlan *, const uint64_t *,
+                               const uint32_t *, uint32_t, uint64_t);
 struct DecodeShape { int tile, threads; DecodeLauncher fn; };
 static const DecodeShape kDecodeShapes[] = {
     {2048, 256, launch_decode_t<2048, 256>}, {1024, 256, launch_decode_t<1024, 256>}, {4096, 256, launch_decode_t<4096, 256>},
@@ -120,9 +120,10 @@ static inline uint64_t decode_tiles_of(uint64_t count, uint32_t kind) {
     const uint64_t t = (uint64_t)decode_config().tile * (kind == ZBRA_ELEM_U32 ? 2 : 1);
     return (count + t - 1) / t;
 }
-static void launch_decode(hipStream_t stream, const DecodePlan *plans, const uint64_t *ts, uint32_t nd, uint64_t ntiles) {
+static void launch_decode(hipStream_t stream, const DecodePlan *plans, const uint64_t *ts, const uint32_t *tmap, uint32_t nd,
+                          uint64_t ntiles) {
     const DecodeConfig &c = decode_config();
-    g_decode_fn(c, grid_for(ntiles, c.grid_cap), stream, plans, ts, nd, ntiles);
+    g_decode_fn(c, grid_for(ntiles, c.grid_cap), stream, plans, ts, tmap, nd, ntiles);
 }
 
 constexpr unsigned STREAM_GRID_CAP = 256 * 8;
@@ -156,14 +157,17 @@ static int decode_batch_dev(DeviceCtx *ctx, const zbra_array_desc *descs, size_t
         uint64_t *tile_start = (uint64_t *)((char *)s->dev + 64);
         hipLaunchKernelGGL(plan_decode_one_kernel, dim3(1), dim3(64), 0, stream, descs[0], ntiles, plan, tile_start,
                            d_results);
-        if (ntiles) launch_decode(stream, plan, tile_start, 1u, ntiles);
+        if (ntiles) launch_decode(stream, plan, tile_start, nullptr, 1u, ntiles);
         int st = hip_status(hipGetLastError());
         int st2 = ctx->release(s, stream);
         return st != ZBRA_OK ? st : st2;
     }
     const size_t off_ts = align_up(nd * sizeof(zbra_array_desc), 64);
     const size_t off_plan = align_up(off_ts + (nd + 1) * sizeof(uint64_t), 64);
-    const size_t total = off_plan + nd * sizeof(DecodePlan);
+    const size_t off_map = align_up(off_plan + nd * sizeof(DecodePlan), 64);
+    uint64_t ntiles = 0;
+    for (size_t i = 0; i < nd; i++) ntiles += decode_tiles_of(descs[i].count, descs[i].kind);
+    const size_t total = off_map + ntiles * sizeof(uint32_t);  // the map lives on the device only
     Slot *s;
     ZBRA_TRY(ctx->acquire(total, &s));
     std::memcpy(s->host, descs, nd * sizeof(zbra_array_desc));
@@ -171,15 +175,15 @@ static int decode_batch_dev(DeviceCtx *ctx, const zbra_array_desc *descs, size_t
     uint64_t run = 0;
     for (size_t i = 0; i < nd; i++) { h_ts[i] = run; run += decode_tiles_of(descs[i].count, descs[i].kind); }
     h_ts[nd] = run;
-    const uint64_t ntiles = run;
     int st = hip_status(hipMemcpyAsync(s->dev, s->host, off_ts + (nd + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, stream));
     if (st == ZBRA_OK) {
         const zbra_array_desc *d_descs = (const zbra_array_desc *)s->dev;
         const uint64_t *d_ts = (const uint64_t *)((char *)s->dev + off_ts);
         DecodePlan *d_plans = (DecodePlan *)((char *)s->dev + off_plan);
-        hipLaunchKernelGGL(plan_decode_batch_kernel, dim3((unsigned)((nd + 255) / 256)), dim3(256), 0, stream, d_descs,
-                           (uint32_t)nd, d_plans, d_results);
-        if (ntiles) launch_decode(stream, d_plans, d_ts, (uint32_t)nd, ntiles);
+        uint32_t *d_map = (uint32_t *)((char *)s->dev + off_map);
+        hipLaunchKernelGGL(plan_decode_batch_kernel, dim3((unsigned)nd), dim3(256), 0, stream, d_descs, (uint32_t)nd, d_ts,
+                           d_plans, d_map, d_results);
+        if (ntiles) launch_decode(stream, d_plans, d_ts, d_map, (uint32_t)nd, ntiles);
         st = hip_status(hipGetLastError());
     }
     int st2 = ctx->release(s, stream);
@@ -505,7 +509,7 @@ int zbra_hip_bp64_unpack(const uint8_t *packed, size_t packed_len, size_t count,
     uint64_t *tile_start = (uint64_t *)((char *)ctx->dev_tmp.ptr + 64);
     hipLaunchKernelGGL(plan_unpack_kernel, dim3(1), dim3(64), 0, ctx->stream, (const uint8_t *)ctx->dev_in.ptr,
                        (uint64_t)packed_len, (uint64_t)count, ctx->dev_out.ptr, ntiles, plan, tile_start);
-    launch_decode(ctx->stream, plan, tile_start, 1u, ntiles);
+    launch_decode(ctx->stream, plan, tile_start, nullptr, 1u, ntiles);
     ZBRA_HIP_TRY(hipGetLastError());
     ZBRA_HIP_TRY(hipMemcpyAsync(out, ctx->dev_out.ptr, count * 8, hipMemcpyDeviceToHost, ctx->stream));
     ZBRA_HIP_TRY(hipStreamSynchronize(ctx->stream));

@@ -52,11 +52,18 @@ __device__ __forceinline__ void plan_one(const zbra_array_desc &d, DecodePlan *p
     if (res) *res = r;
 }
 
-__global__ void plan_decode_batch_kernel(const zbra_array_desc *__restrict__ descs, uint32_t nd,
-                                         DecodePlan *__restrict__ plans, zbra_dev_result *results) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= nd) return;
-    plan_one(descs[i], plans + i, results ? results + i : nullptr);
+// One workgroup per array: lane 0 parses the header, then the workgroup writes the array's index
+// into its slice of the tile -> array table, so that a decode workgroup finds its array with one
+// load instead of a binary search over tile_start (ten dependent loads for a thousand arrays).
+__global__ __launch_bounds__(256) void plan_decode_batch_kernel(const zbra_array_desc *__restrict__ descs, uint32_t nd,
+                                                                const uint64_t *__restrict__ tile_start,
+                                                                DecodePlan *__restrict__ plans, uint32_t *__restrict__ tile_map,
+                                                                zbra_dev_result *results) {
+    const uint32_t a = blockIdx.x;
+    if (a >= nd) return;
+    if (threadIdx.x == 0) plan_one(descs[a], plans + a, results ? results + a : nullptr);
+    const uint64_t t0 = tile_start[a], t1 = tile_start[a + 1];
+    for (uint64_t t = t0 + threadIdx.x; t < t1; t += blockDim.x) tile_map[t] = a;
 }
 
 // Single array: descriptor arrives in the kernel arguments; also writes tile_start = {0, ntiles}.
@@ -332,14 +339,15 @@ __device__ __forceinline__ void decode_tile(const DecodePlan &p, uint64_t tile_i
 // Batched submission: plans come from plan_decode_batch_kernel.
 template <int DT, int TH, int NT, bool DIRECT>
 __global__ __launch_bounds__(TH) void decode_tiles_kernel(const DecodePlan *__restrict__ plans,
-                                                          const uint64_t *__restrict__ tile_start, uint32_t nd,
+                                                          const uint64_t *__restrict__ tile_start,
+                                                          const uint32_t *__restrict__ tile_map, uint32_t nd,
                                                           uint64_t ntiles, uint32_t xcd_chunked) {
     // u32 outputs are half as wide, so their tiles hold twice the values (same bytes written)
     __shared__ __attribute__((aligned(16))) uint32_t lds[lds_dwords<2 * DT>()];
     // xcd_chunked implies gridDim.x == ntiles: exactly one trip through the loop
     uint64_t t = xcd_chunked ? xcd_chunked_tile(blockIdx.x, ntiles) : blockIdx.x;
     for (; t < ntiles; t += gridDim.x) {
-        const uint32_t a = nd > 1 ? find_array(tile_start, nd, t) : 0;
+        const uint32_t a = nd > 1 ? tile_map[t] : 0;
         const DecodePlan p = plans[a];
         decode_tile<DT, TH, NT, DIRECT>(p, t - tile_start[a], lds);
     }
