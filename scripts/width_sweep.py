@@ -1,0 +1,42 @@
+#!/usr/bin/env python3
+"""Decode (and encode) rate per bit width on a single 2^27-row column: finds weak paths."""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+
+from zbra_amd import device, workloads
+
+dev = torch.device("cuda", 0)
+n = 1 << 27
+idx = torch.arange(n, dtype=torch.int64, device=dev)
+rnd = workloads.sm(0xABCDEF, idx)
+del idx
+for bits in [1, 2, 4, 8, 12, 16, 20, 24, 28, 31, 32, 40, 64]:
+    if bits == 64:
+        v = rnd.clone()
+    else:
+        v = (rnd & ((1 << bits) - 1)) - (1 << (bits - 1)) + 1_000_000_007
+    enc = torch.empty(device.encode_bound(n), dtype=torch.uint8, device=dev)
+    res = device.new_results(1, dev)
+    device.encode_dev(v, enc, res)
+    r = device.read_results(res)[0]
+    out = torch.empty_like(v)
+
+    def t(fn, reps=10):
+        fn(); fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / reps
+    dms = t(lambda: device.decode_dev(enc, n, out, None, length=r.out_count))
+    assert torch.equal(out, v)
+    ems = t(lambda: device.encode_dev(v, enc, res), 5)
+    algo = r.out_count + 8 * n
+    print(f"amp bits {bits:2d} -> w {r.width:2d}: decode {dms:.4f} ms {algo / dms / 1e6:6.0f} GB/s ({algo / dms / 8e9:.3f}) | "
+          f"encode {ems:.4f} ms in {8 * n / ems / 1e6:6.0f} GB/s algo ({(16 * n + r.out_count) / ems / 8e9:.3f})")

@@ -139,23 +139,33 @@ __device__ __forceinline__ void store_pair_i64(ZBRA_GLOBAL int64_t *out, uint32_
     }
 }
 
-template <int DT, int TH, int NT>
-__device__ __forceinline__ void tile_packed(const DecodePlan &p, uint64_t v0, uint32_t nv, uint32_t *lds) {
-    const uint32_t tid = threadIdx.x;
+// Where the packed bytes of one tile are: 16-B aligned chunk range and the bit offset of the
+// tile's first value inside it.
+struct PackedSpan {
+    uintptr_t A0;        // 16-B aligned address of the first chunk
+    uint32_t base_bits;  // bit offset of the tile's first value from A0
+    uint32_t nchunks;    // 16-B chunks that hold the tile's bytes
+};
+__device__ __forceinline__ PackedSpan packed_span(const DecodePlan &p, uint64_t v0, uint32_t nv) {
     const uint32_t w = p.width;
     // v0 is a multiple of 8, so the tile starts on a byte of the payload.
     const uintptr_t A = (uintptr_t)p.payload + ((v0 * w) >> 3);
-    const uintptr_t A0 = A & ~(uintptr_t)15;
-    const uint32_t base_bits = (uint32_t)(A - A0) * 8u;
+    PackedSpan s;
+    s.A0 = A & ~(uintptr_t)15;
+    s.base_bits = (uint32_t)(A - s.A0) * 8u;
     const uint32_t nbytes = (nv * w + 7u) >> 3;
-    const uint32_t nchunks = ((uint32_t)(A - A0) + nbytes + 15u) >> 4;
     // Each 16-B aligned chunk holds at least one byte of this array's payload, so it lies inside
     // a mapped page even when the payload itself starts or ends off a 16-B boundary.
-    const ZBRA_GLOBAL u32x4 *src = gptr<u32x4>(A0);
-    u32x4 *dst = (u32x4 *)lds;
-    for (uint32_t c = tid; c < nchunks; c += TH) dst[c] = ld_stream<NT>(src + c);
-    __syncthreads();
+    s.nchunks = ((uint32_t)(A - s.A0) + nbytes + 15u) >> 4;
+    return s;
+}
 
+// LDS image -> values -> 16-B stores, for a tile whose packed bytes are staged in `lds`.
+template <int DT, int TH, int NT>
+__device__ __forceinline__ void packed_extract(const DecodePlan &p, uint64_t v0, uint32_t nv, uint32_t base_bits,
+                                               const uint32_t *lds) {
+    const uint32_t tid = threadIdx.x;
+    const uint32_t w = p.width;
     const uint32_t mask = (1u << w) - 1u;
     if (p.kind != ZBRA_ELEM_U32) {
         ZBRA_GLOBAL int64_t *out = gptr_mut<int64_t>(p.out) + v0;
@@ -196,6 +206,16 @@ __device__ __forceinline__ void tile_packed(const DecodePlan &p, uint64_t v0, ui
             }
         }
     }
+}
+
+template <int DT, int TH, int NT>
+__device__ __forceinline__ void tile_packed(const DecodePlan &p, uint64_t v0, uint32_t nv, uint32_t *lds) {
+    const PackedSpan sp = packed_span(p, v0, nv);
+    const ZBRA_GLOBAL u32x4 *src = gptr<u32x4>(sp.A0);
+    u32x4 *dst = (u32x4 *)lds;
+    for (uint32_t c = threadIdx.x; c < sp.nchunks; c += TH) dst[c] = ld_stream<NT>(src + c);
+    __syncthreads();
+    packed_extract<DT, TH, NT>(p, v0, nv, sp.base_bits, lds);
     __syncthreads();  // a later tile of this workgroup refills the LDS image
 }
 
