@@ -74,10 +74,26 @@ def cpu_baseline(n_sample: int, budget_s: float):
     t1 = time.perf_counter()
     oc.compress_int_array_into(v[:m], buf)
     enc_gbps = 8.0 * m / (time.perf_counter() - t1) / 1e9
+    # all host cores the box gives this job, one independent chunk per thread (ctypes releases the GIL)
+    from concurrent.futures import ThreadPoolExecutor
+    threads = max(1, min(16, len(os.sched_getaffinity(0))))
+    chunk = n_sample // threads
+    parts = [(enc_chunk, np.empty(chunk, dtype=np.int64)) for enc_chunk in
+             (np.frombuffer(oc.compress_int_array(v[i * chunk:(i + 1) * chunk]), dtype=np.uint8).copy() for i in range(threads))]
+    with ThreadPoolExecutor(threads) as pool:
+        t2, rounds = time.perf_counter(), 0
+        while True:
+            list(pool.map(lambda pr: oc.decompress_int_array_into(pr[0], chunk, pr[1]), parts))
+            rounds += 1
+            if time.perf_counter() - t2 >= min(budget_s, 5.0) or rounds >= 200:
+                break
+        all_gbps = 8.0 * chunk * threads * rounds / (time.perf_counter() - t2) / 1e9
     return {"value": round(dec_gbps, 4), "unit": "GB/s", "cores": 1, "kind": "port",
             "sample": f"first 2^{n_sample.bit_length() - 1} rows of the same column, {reps} reps, "
                       f"C restatement of zbra-core compression.rs (gcc -O3), decode only",
-            "encode_GBps": round(enc_gbps, 4)}
+            "encode_GBps": round(enc_gbps, 4),
+            "all_cores": {"value": round(all_gbps, 3), "unit": "GB/s", "cores": threads,
+                          "sample": "same rows cut into one chunk per thread"}}
 
 
 def main():
