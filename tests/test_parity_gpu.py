@@ -156,3 +156,32 @@ def test_large_column_roundtrip_and_oracle(zc, oc):
     assert got == expect
     assert got[12] == 12
     assert np.array_equal(zc.decompress_int_array(got, n), v)
+
+
+def test_encode_select_paths(zc, oc):
+    """Arrays long enough for every route of the median selection: bracket kept as a histogram
+    (narrow), as a candidate list (wide), rejected because the list overflows (few distinct
+    values far apart) or because the sample misleads (periodic data), medians on a run of equal
+    values, and the even-length case whose upper median lies outside the bracket."""
+    rng = np.random.default_rng(77)
+    I64_MIN, I64_MAX = -(1 << 63), (1 << 63) - 1
+    for n in (4097, 131071, 300001, 300002, (1 << 20) + 3):
+        cases = {
+            "narrow": 1_700_000_000_000 + rng.integers(0, 4000, n, dtype=np.int64),
+            "wide": rng.integers(-(1 << 45), 1 << 45, n, dtype=np.int64),
+            "full": rng.integers(I64_MIN, I64_MAX, n, dtype=np.int64, endpoint=True),
+            "two_far": np.where(np.arange(n) % 2 == 0, I64_MIN, I64_MAX).astype(np.int64),
+            "two_near": rng.integers(0, 2, n, dtype=np.int64) * 5000 + 17,
+            "mostly_constant": np.where(rng.random(n) < 0.99, 42, rng.integers(-(1 << 50), 1 << 50, n, dtype=np.int64)),
+            "sorted": np.sort(rng.integers(-(1 << 40), 1 << 40, n, dtype=np.int64)),
+            "reverse_sorted": np.sort(rng.integers(-(1 << 40), 1 << 40, n, dtype=np.int64))[::-1].copy(),
+            "periodic": (np.arange(n, dtype=np.int64) % 73) * (1 << 33),
+            "half_min": np.where(np.arange(n) < n // 2 + 1, I64_MIN, rng.integers(0, 1 << 62, n, dtype=np.int64)),
+            "step": np.where(np.arange(n) < n // 2, -(1 << 61), 1 << 61).astype(np.int64),
+        }
+        for name, v in cases.items():
+            v = np.ascontiguousarray(v, dtype=np.int64)
+            expect = oc.compress_int_array(v)
+            got = zc.compress_int_array(v)
+            assert got[:13] == expect[:13], (name, n, got[:13].hex(), expect[:13].hex())
+            assert got == expect, (name, n)

@@ -7,7 +7,7 @@ import os
 import sys
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libzbra_hip.so")
+LIB_PATH = os.environ.get("ZBRA_HIP_LIB") or os.path.join(_HERE, "libzbra_hip.so")  # override: tuning builds
 
 
 class DevResult(C.Structure):

@@ -127,7 +127,16 @@ static void launch_decode(hipStream_t stream, const DecodePlan *plans, const uin
 }
 
 constexpr unsigned STREAM_GRID_CAP = 256 * 8;
-constexpr unsigned HIST_GRID_CAP = 256 * 4;    // 16 KiB of LDS histogram per workgroup
+
+// ZBRA_HIP_ENCODE_BRACKET=0 turns the sampled bracket off: every array then takes the path a
+// failed bracket takes (min/max pass + radix select over the whole array).  Tuning / test aid.
+static bool encode_bracket_enabled() {
+    static const bool on = [] {
+        const char *e = getenv("ZBRA_HIP_ENCODE_BRACKET");
+        return !(e && atoi(e) == 0);
+    }();
+    return on;
+}
 
 static unsigned pack_grid_cap() {
     static const unsigned cap = [] {
@@ -211,39 +220,69 @@ static int encode_batch_dev(DeviceCtx *ctx, const EncodeItem *items, size_t nd, 
         if (items[i].n && (!items[i].values || (mode == ENCODE_FULL && !items[i].out))) return ZBRA_ERR_INVALID_ARG;
     }
     const size_t off_ts = align_up(nd * sizeof(EncodeJob), 64);
-    const size_t off_hist = align_up(off_ts + (nd + 1) * sizeof(uint64_t), 256);
-    const size_t total = off_hist + nd * BINS * sizeof(uint32_t);
+    const size_t off_list = align_up(off_ts + (nd + 1) * sizeof(uint64_t), 64);  // arrays that may need select passes
+    const size_t off_hist = align_up(off_list + nd * sizeof(uint32_t), 256);
+    const size_t off_ctr = off_hist + nd * BINS * sizeof(uint32_t);  // zeroed together with the histograms
+    const size_t total = off_ctr + nd * sizeof(BracketCounters);
+    // candidate lists of the bracket select: CAND_SEGS segments, n/CAND_DIV values in all, per array
+    // that is long enough for it
+    const bool bracket = encode_bracket_enabled();
+    auto seg_cap_of = [&](const EncodeItem &it) -> uint64_t {
+        if (!bracket || it.kind == KIND_U64_PLAIN || it.n <= (uint64_t)SAMPLE) return 0;
+        return it.n / CAND_DIV / CAND_SEGS / TILE * TILE;
+    };
+    size_t scratch_bytes = 0;
+    for (size_t i = 0; i < nd; i++) scratch_bytes += seg_cap_of(items[i]) * CAND_SEGS * sizeof(int64_t);
     Slot *s;
-    ZBRA_TRY(ctx->acquire(total, &s));
+    ZBRA_TRY(ctx->acquire(total, &s, scratch_bytes));
     EncodeJob *h_jobs = (EncodeJob *)s->host;
     uint64_t *h_ts = (uint64_t *)((char *)s->host + off_ts);
+    uint32_t *h_list = (uint32_t *)((char *)s->host + off_list);
+    uint32_t n_list = 0;
     uint64_t run = 0;
+    size_t scratch_off = 0;
     for (size_t i = 0; i < nd; i++) {
         EncodeJob j;
         std::memset(&j, 0, sizeof(j));
         j.values = items[i].values; j.out = items[i].out; j.n = items[i].n; j.cap = items[i].cap; j.kind = items[i].kind;
         j.min_b = ~0ull; j.max_b = 0; j.next_above = ~0ull;
+        j.sel_values = items[i].values; j.sel_n = items[i].n; j.sel_kind = items[i].kind;
+        j.counters = (BracketCounters *)((char *)s->dev + off_ctr) + i;
+        j.seg_cap = seg_cap_of(items[i]);
+        if (j.seg_cap) {
+            j.cand = (int64_t *)((char *)s->scratch + scratch_off);
+            scratch_off += j.seg_cap * CAND_SEGS * sizeof(int64_t);
+        }
         h_jobs[i] = j;
         h_ts[i] = run;
         run += tiles_of(items[i].n);
+        // arrays of up to SAMPLE values are sorted whole by the sample kernel and need no pass
+        if (items[i].n && items[i].kind != KIND_U64_PLAIN && (!bracket || items[i].n > (uint64_t)SAMPLE)) h_list[n_list++] = (uint32_t)i;
     }
     h_ts[nd] = run;
     const uint64_t ntiles = run;
     EncodeJob *d_jobs = (EncodeJob *)s->dev;
+    const uint32_t *d_list = (const uint32_t *)((char *)s->dev + off_list);
     const uint64_t *d_ts = (const uint64_t *)((char *)s->dev + off_ts);
     uint32_t *d_hist = (uint32_t *)((char *)s->dev + off_hist);
-    int st = hip_status(hipMemcpyAsync(s->dev, s->host, off_ts + (nd + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, stream));
-    if (st == ZBRA_OK) st = hip_status(hipMemsetAsync(d_hist, 0, nd * BINS * sizeof(uint32_t), stream));
+    int st = hip_status(hipMemcpyAsync(s->dev, s->host, off_list + nd * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
+    if (st == ZBRA_OK) st = hip_status(hipMemsetAsync(d_hist, 0, total - off_hist, stream));
     if (st == ZBRA_OK) {
         const unsigned gs = grid_for(ntiles, STREAM_GRID_CAP);
-        const unsigned gh = grid_for(ntiles, HIST_GRID_CAP);
         const unsigned ga = (unsigned)((nd + 255) / 256);
-        if (ntiles) hipLaunchKernelGGL(enc_minmax_kernel, dim3(gs), dim3(THREADS), 0, stream, d_jobs, d_ts, (uint32_t)nd, ntiles);
-        hipLaunchKernelGGL(enc_setup_kernel, dim3(ga), dim3(256), 0, stream, d_jobs, (uint32_t)nd);
+        // workgroups per listed array in the select passes: about 4096 in all, at least 8 each
+        const uint32_t per_array = n_list ? (n_list >= 512 ? 8u : 4096u / n_list) : 1u;
+        if (ntiles) {
+            hipLaunchKernelGGL(enc_sample_kernel, dim3((unsigned)nd), dim3(SAMPLE_THREADS), 0, stream, d_jobs, (uint32_t)nd,
+                               bracket ? 1u : 0u);
+            hipLaunchKernelGGL(enc_bracket_kernel, dim3(gs), dim3(THREADS), 0, stream, d_jobs, d_ts, (uint32_t)nd, ntiles, d_hist);
+        }
+        hipLaunchKernelGGL(enc_setup_kernel, dim3((unsigned)nd), dim3(THREADS), 0, stream, d_jobs, (uint32_t)nd, d_hist);
         if (ntiles) {
             for (uint32_t pass = 0; pass < (uint32_t)MAX_PASSES; pass++) {
-                hipLaunchKernelGGL(enc_hist_kernel, dim3(gh), dim3(THREADS), 0, stream, d_jobs, d_ts, (uint32_t)nd, ntiles,
-                                   d_hist, pass);
+                if (n_list)
+                    hipLaunchKernelGGL(enc_hist_kernel, dim3(n_list * per_array), dim3(THREADS), 0, stream, d_jobs, d_list, n_list,
+                                       per_array, d_hist, pass);
                 hipLaunchKernelGGL(enc_select_kernel, dim3((unsigned)nd), dim3(THREADS), 0, stream, d_jobs, d_hist, pass);
             }
             if (mode == ENCODE_FULL)

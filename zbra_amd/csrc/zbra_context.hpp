@@ -31,6 +31,8 @@ struct Slot {
     void *host = nullptr;
     void *dev = nullptr;
     size_t cap = 0;
+    void *scratch = nullptr;  // device-only memory of the borrower (candidate lists of an encode)
+    size_t scratch_cap = 0;
     hipEvent_t done = nullptr;
     bool busy = false;  // between acquire() and release()
 };
@@ -63,13 +65,20 @@ struct DeviceCtx {
     Arena dev_in, dev_out, dev_tmp;
     Arena pin_in, pin_out;
 
-    int acquire(size_t bytes, Slot **out) {
+    // scratch_bytes of device-only memory come with the slot (grown while the slot is idle).
+    int acquire(size_t bytes, Slot **out, size_t scratch_bytes = 0) {
         std::lock_guard<std::mutex> g(mu);
         for (Slot *s : slots) {
             if (s->busy || s->cap < bytes) continue;
             if (hipEventQuery(s->done) != hipSuccess) {
                 (void)hipGetLastError();  // hipErrorNotReady is not a failure
                 continue;
+            }
+            if (s->scratch_cap < scratch_bytes) {
+                if (s->scratch) ZBRA_HIP_TRY(hipFree(s->scratch));
+                s->scratch = nullptr; s->scratch_cap = 0;
+                ZBRA_HIP_TRY(hipMalloc(&s->scratch, scratch_bytes));
+                s->scratch_cap = scratch_bytes;
             }
             s->busy = true;
             *out = s;
@@ -79,10 +88,15 @@ struct DeviceCtx {
         size_t cap = bytes < 4096 ? 4096 : bytes;
         hipError_t e = hipHostMalloc(&s->host, cap, hipHostMallocDefault);
         if (e == hipSuccess) e = hipMalloc(&s->dev, cap);
+        if (e == hipSuccess && scratch_bytes) {
+            e = hipMalloc(&s->scratch, scratch_bytes);
+            if (e == hipSuccess) s->scratch_cap = scratch_bytes;
+        }
         if (e == hipSuccess) e = hipEventCreateWithFlags(&s->done, hipEventDisableTiming);
         if (e != hipSuccess) {
             if (s->host) (void)hipHostFree(s->host);
             if (s->dev) (void)hipFree(s->dev);
+            if (s->scratch) (void)hipFree(s->scratch);
             delete s;
             return hip_status(e);
         }

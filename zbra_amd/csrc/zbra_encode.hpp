@@ -5,14 +5,23 @@
 // and bp64_pack (:117-178, max scan + byte-at-a-time bit buffer).
 //
 // The bytes are a function of (midpoint, width) only, so the device needs, per array:
-//   1. min / max                                   -> key space [0, span], span = max - min
-//   2. the (n-1)/2-th smallest value a, and for even n the next one b
-//                                                   -> radix select on key = v - min, 12 bits a pass,
-//                                                      ceil(bits(span)/12) passes (1 for spans < 4096)
-//   3. midpoint = a, or a + trunc((b - a)/2)        (compression.rs:60-68)
-//   4. width = bit length of max zigzag(v - mid)    from the two extremes when span < 2^63 (no
+//   1. min / max, and the (n-1)/2-th smallest value a (for even n also the next one, b), exactly;
+//   2. midpoint = a, or a + trunc((b - a)/2)        (compression.rs:60-68)
+//   3. width = bit length of max zigzag(v - mid)    from the two extremes when span < 2^63 (no
 //                                                   wrap-around possible), else from an OR pass
-//   5. the packed stream.
+//   4. the packed stream.
+// Selection reads the array ONCE in the common case:
+//   sample   4096 pseudo-randomly placed values are sorted in LDS; the values 192 sample ranks
+//            either side of the median's expected sample rank (6 sigma) bracket the median.
+//            Arrays of up to 4096 values are sorted whole: a, b, min and max fall out directly.
+//   bracket  one pass counts the values below the bracket, finds min / max and the smallest value
+//            above the bracket, and keeps what is inside it: as a histogram when the bracket spans
+//            fewer than 4096 distinct keys, else as a compacted list (about 9 % of the array).
+//   verify   the exact counts say whether ranks (n-1)/2 and n/2 are inside the bracket.  If so the
+//            radix select below runs on the histogram / the compacted list; if not (a sample that
+//            misled, more than n/4 candidates) it runs on the whole array, as it would without
+//            the sample.  Either way the result is exact.
+//   select   radix select on key = v - base, 12 bits a pass, ceil(bits(span)/12) passes.
 // Every kernel works on a whole submission (many arrays) through the same tile -> array map the
 // decoder uses, and every pass that an array does not need skips that array's memory.
 #pragma once
@@ -43,7 +52,46 @@ struct EncodeJob {
     int64_t midpoint;
     uint32_t width;
     uint32_t need_or;
+    // bracket select
+    uint32_t mode;       // SelectMode
+    uint32_t reserved0;
+    uint64_t lo_b, hi_b; // bracket, inclusive, in biased (v ^ SIGN) space
+    uint64_t below, inb; // exact counts of values below / inside the bracket (summed by the setup kernel)
+    uint64_t key_base;   // keys of the radix select are (v ^ SIGN) - key_base
+    const void *sel_values;  // what the radix select reads: the array itself or its candidates
+    uint64_t sel_n;
+    uint32_t sel_kind;
+    uint32_t reserved;
+    // Candidate list (values inside the bracket): CAND_SEGS segments of seg_cap entries, segment s
+    // filled from its start with counters->slot[s].cand_count entries.  Appends rotate over the
+    // segments, so that they (and the below / inside counts, which live in the same slots) queue
+    // on CAND_SEGS different cache lines instead of one.
+    int64_t *cand;
+    uint64_t seg_cap;    // a multiple of TILE; 0 = no list (short array or bracket select off)
+    struct BracketCounters *counters;
 };
+
+constexpr int CAND_SEGS = 16;
+struct BracketCounters {
+    struct Slot {
+        unsigned long long below, inb, cand_count;  // cand_count may exceed seg_cap: the list is then unusable
+        unsigned long long pad[5];
+    } slot[CAND_SEGS];
+};
+static_assert(sizeof(BracketCounters::Slot) == 64, "one slot per 64-byte line");
+
+enum SelectMode : uint32_t {
+    SEL_FULL = 0,            // no bracket: min/max pass, then radix select over the whole array
+    SEL_BRACKET_HIST = 1,    // bracket narrower than BINS keys: histogram filled by the bracket pass
+    SEL_BRACKET_COMPACT = 2, // wide bracket: candidates compacted by the bracket pass
+    SEL_DONE = 3             // midpoint and width already known (small array sorted whole, constant, ...)
+};
+
+constexpr int SAMPLE = 4096;          // sample keys sorted in LDS (32 KiB)
+constexpr int SAMPLE_THREADS = 1024;  // lanes of the sorting workgroup
+constexpr int SAMPLE_MARGIN = 192;    // sample ranks either side: 6 sigma, sigma = sqrt(SAMPLE)/2 = 32
+constexpr int CAND_DIV = 4;           // candidate list capacity = n / CAND_DIV (a bracket holds ~9 % of n)
+constexpr int CAND_LDS = 2048;        // candidates a workgroup stages in LDS between flushes (>= 1 tile)
 
 __device__ __forceinline__ int64_t load_value(const EncodeJob &j, uint64_t i) {
     return j.kind != ZBRA_ELEM_U32 ? gptr<int64_t>(j.values)[i] : (int64_t)gptr<uint32_t>(j.values)[i];
@@ -76,18 +124,19 @@ constexpr int PAIRS = TILE / (THREADS * 2);  // 16-B loads per thread per tile
 // This thread's 2*PAIRS values of the tile that starts at value v0: x[2*it], x[2*it+1] are values
 // v0 + it*2*THREADS + 2*tid (+1).  A tile that lies wholly inside the array issues all its loads
 // back to back; values past n get `fill`.
-__device__ __forceinline__ void load_tile(const EncodeJob &j, uint64_t v0, uint64_t n, int64_t fill, int64_t (&x)[2 * PAIRS]) {
+__device__ __forceinline__ void load_tile_from(const void *values, uint32_t kind, uint64_t v0, uint64_t n, int64_t fill,
+                                               int64_t (&x)[2 * PAIRS]) {
     const uint32_t tid = threadIdx.x;
     if (v0 + TILE <= n) {  // uniform
-        if (j.kind != ZBRA_ELEM_U32) {
-            const ZBRA_GLOBAL u64x2 *src = (const ZBRA_GLOBAL u64x2 *)(gptr<int64_t>(j.values) + v0) + tid;
+        if (kind != ZBRA_ELEM_U32) {
+            const ZBRA_GLOBAL u64x2 *src = (const ZBRA_GLOBAL u64x2 *)(gptr<int64_t>(values) + v0) + tid;
             u64x2 v[PAIRS];
 #pragma unroll
             for (int it = 0; it < PAIRS; ++it) v[it] = __builtin_nontemporal_load(src + it * THREADS);
 #pragma unroll
             for (int it = 0; it < PAIRS; ++it) { x[2 * it] = (int64_t)v[it].x; x[2 * it + 1] = (int64_t)v[it].y; }
         } else {
-            const ZBRA_GLOBAL u32x2 *src = (const ZBRA_GLOBAL u32x2 *)(gptr<uint32_t>(j.values) + v0) + tid;
+            const ZBRA_GLOBAL u32x2 *src = (const ZBRA_GLOBAL u32x2 *)(gptr<uint32_t>(values) + v0) + tid;
             u32x2 v[PAIRS];
 #pragma unroll
             for (int it = 0; it < PAIRS; ++it) v[it] = __builtin_nontemporal_load(src + it * THREADS);
@@ -95,9 +144,14 @@ __device__ __forceinline__ void load_tile(const EncodeJob &j, uint64_t v0, uint6
             for (int it = 0; it < PAIRS; ++it) { x[2 * it] = (int64_t)v[it].x; x[2 * it + 1] = (int64_t)v[it].y; }
         }
     } else {
+        EncodeJob view;
+        view.values = values; view.kind = kind;
 #pragma unroll
-        for (int it = 0; it < PAIRS; ++it) load_pair(j, v0 + it * THREADS * 2 + tid * 2, n, fill, x[2 * it], x[2 * it + 1]);
+        for (int it = 0; it < PAIRS; ++it) load_pair(view, v0 + it * THREADS * 2 + tid * 2, n, fill, x[2 * it], x[2 * it + 1]);
     }
+}
+__device__ __forceinline__ void load_tile(const EncodeJob &j, uint64_t v0, uint64_t n, int64_t fill, int64_t (&x)[2 * PAIRS]) {
+    load_tile_from(j.values, j.kind, v0, n, fill, x);
 }
 
 __device__ __forceinline__ uint64_t wave_min_u64(uint64_t v) {
@@ -136,47 +190,14 @@ __device__ __forceinline__ void for_each_array_run(const uint64_t *__restrict__ 
     }
 }
 
-// ---- 1. min / max --------------------------------------------------------------------------
-
-__global__ __launch_bounds__(THREADS) void enc_minmax_kernel(EncodeJob *__restrict__ jobs,
-                                                              const uint64_t *__restrict__ tile_start, uint32_t nd,
-                                                              uint64_t ntiles) {
-    for_each_array_run(tile_start, nd, ntiles, [&](uint32_t a, uint64_t a_first, uint64_t t0, uint64_t t1) {
-        const EncodeJob &job = jobs[a];
-        if (job.kind == KIND_U64_PLAIN) return;
-        const uint64_t n = job.n;
-        uint64_t lo = ~0ull, hi = 0;
-        for (uint64_t t = t0; t < t1; ++t) {
-            const uint64_t v0 = (t - a_first) * TILE;
-            int64_t x[2 * PAIRS];
-            // fill = the array's first value: a no-op for both min and max
-            load_tile(job, v0, n, load_value(job, 0), x);
-#pragma unroll
-            for (int e = 0; e < 2 * PAIRS; ++e) {
-                const uint64_t b = (uint64_t)x[e] ^ SIGN;
-                lo = min(lo, b);
-                hi = max(hi, b);
-            }
-        }
-        lo = wave_min_u64(lo);
-        hi = wave_max_u64(hi);
-        if ((threadIdx.x & 63) == 0) {
-            // most waves cannot improve on what is already there: look before adding to the queue
-            // on these two words (a stale look only costs an atomic that changes nothing)
-            unsigned long long *pmin = (unsigned long long *)&jobs[a].min_b, *pmax = (unsigned long long *)&jobs[a].max_b;
-            if (lo < __hip_atomic_load(pmin, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMin(pmin, (unsigned long long)lo);
-            if (hi > __hip_atomic_load(pmax, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(pmax, (unsigned long long)hi);
-        }
-    });
-}
-
-// ---- 2. radix select ---------------------------------------------------------------------
+// ---- helpers ---------------------------------------------------------------------------------
 
 __device__ __forceinline__ uint32_t bit_length64(uint64_t x) { return x ? 64u - (uint32_t)__builtin_clzll(x) : 0u; }
 
 // bp64_pack's width rule (compression.rs:123-128) from max zig-zag value.
 __device__ __forceinline__ uint32_t width_of(uint64_t zmax) { return zmax ? bit_length64(zmax) : 1u; }
 
+// Needs j.min_b / j.max_b / j.need_or.
 __device__ __forceinline__ void set_midpoint(EncodeJob &j, int64_t a, int64_t b, bool even) {
     int64_t mid = a;
     if (even) {
@@ -192,71 +213,351 @@ __device__ __forceinline__ void set_midpoint(EncodeJob &j, int64_t a, int64_t b,
     }
 }
 
-__global__ void enc_setup_kernel(EncodeJob *__restrict__ jobs, uint32_t nd) {
-    const uint32_t a = blockIdx.x * blockDim.x + threadIdx.x;
+// ---- 1. sample: bracket the median (or finish small arrays outright) --------------------------
+
+// Bitonic sort of SAMPLE keys in LDS by one workgroup of SAMPLE_THREADS lanes.
+__device__ __forceinline__ void sort_keys_lds(uint64_t *sk) {
+    for (uint32_t size = 2; size <= (uint32_t)SAMPLE; size <<= 1) {
+        for (uint32_t stride = size >> 1; stride > 0; stride >>= 1) {
+            __syncthreads();
+            for (uint32_t t = threadIdx.x; t < (uint32_t)SAMPLE / 2; t += SAMPLE_THREADS) {
+                const uint32_t lo = 2 * t - (t & (stride - 1));  // index of the lower partner
+                const uint32_t hi = lo + stride;
+                const bool up = (lo & size) == 0;
+                const uint64_t x = sk[lo], y = sk[hi];
+                if ((x > y) == up) { sk[lo] = y; sk[hi] = x; }
+            }
+        }
+    }
+    __syncthreads();
+}
+
+// One workgroup per array.
+__global__ __launch_bounds__(SAMPLE_THREADS) void enc_sample_kernel(EncodeJob *__restrict__ jobs, uint32_t nd, uint32_t use_bracket) {
+    __shared__ uint64_t sk[SAMPLE];
+    const uint32_t a = blockIdx.x;
     if (a >= nd) return;
-    EncodeJob &j = jobs[a];
-    if (j.n == 0) { j.passes = 0; return; }
-    if (j.kind == KIND_U64_PLAIN) { j.passes = 0; j.need_or = 1; j.midpoint = 0; return; }
-    const uint64_t span = j.max_b - j.min_b;
-    j.passes = (bit_length64(span) + DIGIT_BITS - 1) / DIGIT_BITS;
-    j.need_or = span >= SIGN;
-    j.k = (j.n - 1) / 2;  // rank of a: n/2 - 1 for even n, n/2 for odd n
-    j.prefix = 0;
-    if (j.passes == 0) {  // constant column
-        const int64_t v = (int64_t)(j.min_b ^ SIGN);
-        set_midpoint(j, v, v, false);
+    EncodeJob &job = jobs[a];
+    const uint64_t n = job.n;
+    if (n == 0 || job.kind == KIND_U64_PLAIN || !use_bracket) return;  // mode stays SEL_FULL; setup deals with it
+
+    const bool whole = n <= (uint64_t)SAMPLE;
+    const uint64_t stride = whole ? 1 : n / SAMPLE;
+    for (uint32_t j = threadIdx.x; j < (uint32_t)SAMPLE; j += SAMPLE_THREADS) {
+        uint64_t key = ~0ull;  // padding of a short array sorts to the end
+        if (whole) {
+            if (j < n) key = (uint64_t)load_value(job, j) ^ SIGN;
+        } else {
+            // one value from each of SAMPLE equal strides, at a hashed offset inside it, so that
+            // periodic data does not alias with the sampling step
+            uint64_t h = (j + 1) * 0x9E3779B97F4A7C15ull;
+            h ^= h >> 29; h *= 0xBF58476D1CE4E5B9ull; h ^= h >> 32;
+            key = (uint64_t)load_value(job, (uint64_t)j * stride + h % stride) ^ SIGN;
+        }
+        sk[j] = key;
+    }
+    sort_keys_lds(sk);
+    if (threadIdx.x != 0) return;
+    const uint64_t k = (n - 1) / 2;  // rank of a: n/2 - 1 for even n, n/2 for odd n
+    if (whole) {
+        job.min_b = sk[0]; job.max_b = sk[n - 1];
+        job.need_or = job.max_b - job.min_b >= SIGN;
+        job.passes = 0;
+        job.mode = SEL_DONE;
+        const bool even = (n & 1) == 0;
+        set_midpoint(job, (int64_t)(sk[k] ^ SIGN), (int64_t)(sk[even ? k + 1 : k] ^ SIGN), even);
+        return;
+    }
+    const uint64_t r = (uint64_t)(((unsigned __int128)k * SAMPLE) / n);  // expected sample rank of a
+    job.lo_b = r >= (uint64_t)SAMPLE_MARGIN ? sk[r - SAMPLE_MARGIN] : 0;
+    job.hi_b = r + SAMPLE_MARGIN < (uint64_t)SAMPLE ? sk[r + SAMPLE_MARGIN] : ~0ull;
+    if (job.hi_b - job.lo_b < (uint64_t)BINS) job.mode = SEL_BRACKET_HIST;
+    else if (job.seg_cap) job.mode = SEL_BRACKET_COMPACT;  // else stays SEL_FULL: no room for candidates
+}
+
+// ---- 2. bracket pass: min / max, counts, histogram or candidates — one read of the array ------
+
+// Per-lane accumulators of one run of tiles of one array.
+struct BracketAcc {
+    uint64_t lo = ~0ull, hi = 0, above = ~0ull;
+    uint32_t below = 0, inb = 0;
+};
+
+// Values x[E0..E1) of a tile.  MODE and WHOLE (the tile lies wholly inside the array) are
+// compile-time so that the loop body is straight-line code with one branch (the append).
+template <uint32_t MODE, bool WHOLE, int E0, int E1>
+__device__ __forceinline__ void bracket_values(const int64_t (&x)[2 * PAIRS], uint64_t v0, uint64_t n, uint64_t lo_b,
+                                               uint64_t hi_b, BracketAcc &acc, uint32_t *lh, int64_t *lcand, uint32_t *lcount) {
+#pragma unroll
+    for (int e = E0; e < E1; ++e) {
+        const uint64_t b = (uint64_t)x[e] ^ SIGN;
+        acc.lo = min(acc.lo, b);  // lanes past the end hold a value of the array: harmless here
+        acc.hi = max(acc.hi, b);
+        if (MODE != SEL_FULL) {
+            const bool valid = WHOLE || v0 + (e >> 1) * THREADS * 2 + threadIdx.x * 2 + (e & 1) < n;
+            const bool is_below = valid && b < lo_b, is_above = valid && b > hi_b;
+            const bool inside = valid && !is_below && !is_above;
+            acc.below += is_below;
+            acc.inb += inside;
+            acc.above = is_above && b < acc.above ? b : acc.above;
+            if (inside) {
+                if (MODE == SEL_BRACKET_HIST) atomicAdd(&lh[(uint32_t)(b - lo_b)], 1u);
+                else lcand[atomicAdd(lcount, 1u)] = x[e];
+            }
+        }
     }
 }
 
-// Histogram of digit `pass` of the keys that share the resolved prefix.
-__global__ __launch_bounds__(THREADS) void enc_hist_kernel(EncodeJob *__restrict__ jobs,
-                                                            const uint64_t *__restrict__ tile_start, uint32_t nd,
-                                                            uint64_t ntiles, uint32_t *__restrict__ hist, uint32_t pass) {
-    __shared__ uint32_t lh[BINS];
+__global__ __launch_bounds__(THREADS) void enc_bracket_kernel(EncodeJob *__restrict__ jobs,
+                                                               const uint64_t *__restrict__ tile_start, uint32_t nd,
+                                                               uint64_t ntiles, uint32_t *__restrict__ hist) {
+    // An array is in histogram mode or in candidate mode, never both: the two images share LDS.
+    // Invariant between runs: the histogram part is all zero.
+    __shared__ __attribute__((aligned(16))) int64_t pool[CAND_LDS];
+    static_assert(sizeof(int64_t) * CAND_LDS >= sizeof(uint32_t) * BINS && CAND_LDS >= TILE, "LDS pool too small");
+    uint32_t *lh = (uint32_t *)pool;
+    int64_t *lcand = pool;
+    __shared__ uint32_t lcount;                 // candidates staged in lcand
+    __shared__ unsigned long long lbelow, linb; // this run's counts
+    __shared__ unsigned long long lbase;        // where a flush goes in the global list
     for (uint32_t b = threadIdx.x; b < BINS; b += THREADS) lh[b] = 0;
+    if (threadIdx.x == 0) { lcount = 0; lbelow = 0; linb = 0; }
     __syncthreads();
     for_each_array_run(tile_start, nd, ntiles, [&](uint32_t a, uint64_t a_first, uint64_t t0, uint64_t t1) {
         const EncodeJob &job = jobs[a];
-        if (pass >= job.passes) return;  // uniform
-        const uint64_t n = job.n;
-        const uint32_t shift = DIGIT_BITS * (job.passes - 1 - pass);
-        const bool last = pass + 1 == job.passes;
-        const uint64_t prefix = job.prefix;
-        const uint64_t vmin_b = job.min_b;
-        uint64_t above = ~0ull;
+        const uint32_t mode = job.mode;
+        if (job.kind == KIND_U64_PLAIN || mode == SEL_DONE) return;  // uniform
+        const void *values = job.values;
+        const uint32_t kind = job.kind;
+        const uint64_t n = job.n, seg_cap = job.seg_cap;
+        // counts go to the slot of this workgroup; candidate flushes rotate over the segments, so
+        // that a short array that only two or three workgroups see still fills all of them evenly
+        BracketCounters::Slot *ctr = &job.counters->slot[blockIdx.x % CAND_SEGS];
+        uint32_t flushes = 0;
+        const uint64_t lo_b = job.lo_b, hi_b = job.hi_b;
+        const int64_t fill = load_value(job, 0);  // a value of the array: a no-op for min and max
+        BracketAcc acc;
+        auto flush_candidates = [&]() {  // all lanes; lcount candidates -> global list
+            __syncthreads();
+            const uint32_t cnt = lcount;
+            if (cnt) {
+                const uint32_t sgm = (blockIdx.x + flushes++) % CAND_SEGS;
+                if (threadIdx.x == 0)
+                    lbase = atomicAdd(&job.counters->slot[sgm].cand_count, (unsigned long long)cnt);
+                __syncthreads();
+                const uint64_t base = lbase;
+                if (base + cnt <= seg_cap) {
+                    ZBRA_GLOBAL int64_t *dst = gptr_mut<int64_t>(job.cand) + (size_t)sgm * seg_cap + base;
+                    for (uint32_t i = threadIdx.x; i < cnt; i += THREADS) dst[i] = lcand[i];
+                }
+                __syncthreads();
+                if (threadIdx.x == 0) lcount = 0;
+                __syncthreads();
+            }
+        };
         for (uint64_t t = t0; t < t1; ++t) {
             const uint64_t v0 = (t - a_first) * TILE;
+            const bool whole = v0 + TILE <= n;  // uniform
             int64_t x[2 * PAIRS];
-            load_tile(job, v0, n, 0, x);
-#pragma unroll
-            for (int e = 0; e < 2 * PAIRS; ++e) {
-                const uint64_t i = v0 + (e >> 1) * THREADS * 2 + threadIdx.x * 2 + (e & 1);
-                if (i < n) {
-                    const uint64_t key = ((uint64_t)x[e] ^ SIGN) - vmin_b;
-                    if (pass == 0) {
-                        atomicAdd(&lh[(uint32_t)(key >> shift)], 1u);
-                    } else {
-                        const uint64_t high = key >> (shift + DIGIT_BITS);
-                        if (high == prefix) atomicAdd(&lh[(uint32_t)(key >> shift) & (BINS - 1)], 1u);
-                        else if (last && high > prefix) above = min(above, key);
-                    }
+            load_tile_from(values, kind, v0, n, fill, x);
+            if (mode == SEL_FULL) {
+                bracket_values<SEL_FULL, true, 0, 2 * PAIRS>(x, v0, n, lo_b, hi_b, acc, lh, lcand, &lcount);
+            } else if (mode == SEL_BRACKET_HIST) {
+                if (whole) bracket_values<SEL_BRACKET_HIST, true, 0, 2 * PAIRS>(x, v0, n, lo_b, hi_b, acc, lh, lcand, &lcount);
+                else bracket_values<SEL_BRACKET_HIST, false, 0, 2 * PAIRS>(x, v0, n, lo_b, hi_b, acc, lh, lcand, &lcount);
+            } else {
+                // the LDS list takes half a tile's worth of appends between two looks at its fill
+                __syncthreads();  // every lane must see the same count, or the flush would split the workgroup
+                if (lcount + TILE / 2 > (uint32_t)CAND_LDS) flush_candidates();
+                if (whole) bracket_values<SEL_BRACKET_COMPACT, true, 0, PAIRS>(x, v0, n, lo_b, hi_b, acc, lh, lcand, &lcount);
+                else bracket_values<SEL_BRACKET_COMPACT, false, 0, PAIRS>(x, v0, n, lo_b, hi_b, acc, lh, lcand, &lcount);
+                __syncthreads();
+                if (lcount + TILE / 2 > (uint32_t)CAND_LDS) flush_candidates();
+                if (whole) bracket_values<SEL_BRACKET_COMPACT, true, PAIRS, 2 * PAIRS>(x, v0, n, lo_b, hi_b, acc, lh, lcand, &lcount);
+                else bracket_values<SEL_BRACKET_COMPACT, false, PAIRS, 2 * PAIRS>(x, v0, n, lo_b, hi_b, acc, lh, lcand, &lcount);
+            }
+        }
+        // min / max: most waves cannot improve on what is already there: look before queueing an
+        // atomic on these two words (a stale look only costs an atomic that changes nothing)
+        const uint64_t lo = wave_min_u64(acc.lo), hi = wave_max_u64(acc.hi);
+        if ((threadIdx.x & 63) == 0) {
+            unsigned long long *pmin = (unsigned long long *)&jobs[a].min_b, *pmax = (unsigned long long *)&jobs[a].max_b;
+            if (lo < __hip_atomic_load(pmin, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMin(pmin, (unsigned long long)lo);
+            if (hi > __hip_atomic_load(pmax, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(pmax, (unsigned long long)hi);
+        }
+        if (mode != SEL_FULL) {
+            if (acc.below) atomicAdd(&lbelow, (unsigned long long)acc.below);
+            if (acc.inb) atomicAdd(&linb, (unsigned long long)acc.inb);
+            const uint64_t above = wave_min_u64(acc.above);
+            if ((threadIdx.x & 63) == 0) {
+                unsigned long long *pabove = (unsigned long long *)&jobs[a].next_above;
+                if (above < __hip_atomic_load(pabove, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMin(pabove, (unsigned long long)above);
+            }
+            if (mode == SEL_BRACKET_COMPACT) {
+                flush_candidates();
+                for (uint32_t b = threadIdx.x; b < BINS; b += THREADS) lh[b] = 0;  // restore the invariant
+            }
+            __syncthreads();
+            if (mode == SEL_BRACKET_HIST) {
+                uint32_t *gh = hist + (size_t)a * BINS;
+                for (uint32_t b = threadIdx.x; b < BINS; b += THREADS) {
+                    const uint32_t c = lh[b];
+                    if (c) { atomicAdd(&gh[b], c); lh[b] = 0; }
+                }
+            }
+            if (threadIdx.x == 0) {
+                if (lbelow) atomicAdd(&ctr->below, lbelow);
+                if (linb) atomicAdd(&ctr->inb, linb);
+                lbelow = 0; linb = 0;
+            }
+            __syncthreads();
+        }
+    });
+}
+
+// ---- 3. verify the bracket, set up the radix select -------------------------------------------
+
+// One workgroup per array.
+__global__ __launch_bounds__(THREADS) void enc_setup_kernel(EncodeJob *__restrict__ jobs, uint32_t nd,
+                                                             uint32_t *__restrict__ hist) {
+    const uint32_t a = blockIdx.x;
+    if (a >= nd) return;
+    EncodeJob &j = jobs[a];
+    __shared__ uint32_t clear_hist;
+    if (threadIdx.x == 0) {
+        clear_hist = 0;
+        if (j.n == 0) {
+            j.passes = 0;
+        } else if (j.kind == KIND_U64_PLAIN) {
+            j.passes = 0; j.need_or = 1; j.midpoint = 0;
+        } else if (j.mode != SEL_DONE) {
+            const uint64_t span = j.max_b - j.min_b;
+            j.need_or = span >= SIGN;
+            j.prefix = 0;
+            const uint64_t k = (j.n - 1) / 2;  // rank of a: n/2 - 1 for even n, n/2 for odd n
+            bool whole_list = true;
+            if (j.mode != SEL_FULL) {
+                j.below = 0; j.inb = 0;
+                for (int sgm = 0; sgm < CAND_SEGS; sgm++) {
+                    j.below += j.counters->slot[sgm].below;
+                    j.inb += j.counters->slot[sgm].inb;
+                    whole_list = whole_list && j.counters->slot[sgm].cand_count <= j.seg_cap;
+                }
+            }
+            // Rank k must fall inside the bracket (rank k+1, for even n, may also be the smallest
+            // value above it), and the candidate list must be whole.
+            bool ok = j.mode != SEL_FULL && k >= j.below && k < j.below + j.inb;
+            if (ok && j.mode == SEL_BRACKET_COMPACT) ok = whole_list;
+            if (ok) {
+                // the histogram was built on keys b - lo_b; a candidate list may use the tighter base
+                j.key_base = j.mode == SEL_BRACKET_HIST || j.lo_b > j.min_b ? j.lo_b : j.min_b;
+                j.k = k - j.below;
+                if (j.next_above != ~0ull) j.next_above -= j.key_base;  // into key space
+                const uint64_t bspan = (j.hi_b < j.max_b ? j.hi_b : j.max_b) - j.key_base;
+                j.passes = (bit_length64(bspan) + DIGIT_BITS - 1) / DIGIT_BITS;
+                if (j.passes == 0) j.passes = 1;  // a one-key bracket still goes through select
+                if (j.mode == SEL_BRACKET_HIST) {
+                    j.passes = 1;  // the bracket pass already filled the histogram: select only
+                    j.sel_values = j.values; j.sel_n = 0; j.sel_kind = j.kind;  // nothing left to read
+                } else {
+                    // the segmented list, seen as one index space with gaps
+                    j.sel_values = j.cand; j.sel_n = j.seg_cap * CAND_SEGS; j.sel_kind = ZBRA_ELEM_I64;
+                }
+            } else {
+                if (j.mode == SEL_BRACKET_HIST) clear_hist = 1;
+                j.mode = SEL_FULL;
+                j.key_base = j.min_b;
+                j.k = k;
+                j.next_above = ~0ull;
+                j.passes = (bit_length64(span) + DIGIT_BITS - 1) / DIGIT_BITS;
+                j.sel_values = j.values; j.sel_n = j.n; j.sel_kind = j.kind;
+                if (j.passes == 0) {  // constant column
+                    const int64_t v = (int64_t)(j.min_b ^ SIGN);
+                    set_midpoint(j, v, v, false);
                 }
             }
         }
-        __syncthreads();
-        uint32_t *gh = hist + (size_t)a * BINS;
-        for (uint32_t b = threadIdx.x; b < BINS; b += THREADS) {
-            const uint32_t c = lh[b];
-            if (c) { atomicAdd(&gh[b], c); lh[b] = 0; }
+    }
+    __syncthreads();
+    if (clear_hist)
+        for (uint32_t b = threadIdx.x; b < BINS; b += THREADS) hist[(size_t)a * BINS + b] = 0;
+}
+
+// ---- 4. radix select ---------------------------------------------------------------------
+
+// Digit `pass` of key into the workgroup's LDS histogram, if the key shares the resolved prefix.
+__device__ __forceinline__ void hist_key(uint32_t *lh, uint64_t key, uint32_t pass, uint32_t shift, uint64_t prefix, bool last,
+                                         uint64_t &above) {
+    if (pass == 0) {
+        atomicAdd(&lh[(uint32_t)(key >> shift)], 1u);
+    } else {
+        const uint64_t high = key >> (shift + DIGIT_BITS);
+        if (high == prefix) atomicAdd(&lh[(uint32_t)(key >> shift) & (BINS - 1)], 1u);
+        else if (last && high > prefix) above = min(above, key);
+    }
+}
+
+// Histogram of digit `pass` of the keys that share the resolved prefix, over what each array's
+// select reads: the whole array (tiles of TILE values) or its candidate list (segments, each
+// filled from its start).  `list` names the arrays that can need a pass at all (the host knows
+// which are too short to); workgroup (i, w) of `per_array` workgroups per listed array takes tiles
+// w, w + per_array, ... of array list[i], so an array that needs many passes is never left to the
+// two or three workgroups that happen to own its stretch of the submission.
+__global__ __launch_bounds__(THREADS) void enc_hist_kernel(EncodeJob *__restrict__ jobs, const uint32_t *__restrict__ list,
+                                                            uint32_t n_list, uint32_t per_array,
+                                                            uint32_t *__restrict__ hist, uint32_t pass) {
+    const uint32_t li = blockIdx.x / per_array, w = blockIdx.x % per_array;
+    if (li >= n_list) return;
+    const uint32_t a = list[li];
+    const EncodeJob &job = jobs[a];
+    const uint32_t mode = job.mode;
+    if ((mode != SEL_FULL && mode != SEL_BRACKET_COMPACT) || pass >= job.passes) return;
+    __shared__ uint32_t lh[BINS];
+    for (uint32_t b = threadIdx.x; b < BINS; b += THREADS) lh[b] = 0;
+    __syncthreads();
+    const uint32_t shift = DIGIT_BITS * (job.passes - 1 - pass);
+    const bool last = pass + 1 == job.passes;
+    const uint64_t prefix = job.prefix, base = job.key_base;
+    uint64_t above = ~0ull;
+    if (mode == SEL_FULL) {
+        const void *values = job.values;
+        const uint32_t kind = job.kind;
+        const uint64_t n = job.n;
+        for (uint64_t v0 = (uint64_t)w * TILE; v0 < n; v0 += (uint64_t)per_array * TILE) {
+            int64_t x[2 * PAIRS];
+            load_tile_from(values, kind, v0, n, 0, x);
+#pragma unroll
+            for (int e = 0; e < 2 * PAIRS; ++e) {
+                const uint64_t i = v0 + (e >> 1) * THREADS * 2 + threadIdx.x * 2 + (e & 1);
+                if (i < n) hist_key(lh, ((uint64_t)x[e] ^ SIGN) - base, pass, shift, prefix, last, above);
+            }
         }
-        if (last && pass > 0) {
-            above = wave_min_u64(above);
-            if ((threadIdx.x & 63) == 0 && above != ~0ull)
-                atomicMin((unsigned long long *)&jobs[a].next_above, (unsigned long long)above);
+    } else {
+        const uint64_t seg_cap = job.seg_cap, seg_tiles = seg_cap / TILE;
+        for (uint64_t u = w; u < seg_tiles * CAND_SEGS; u += per_array) {
+            const uint64_t sgm = u % CAND_SEGS, v0 = sgm * seg_cap + (u / CAND_SEGS) * TILE;
+            const uint64_t end = sgm * seg_cap + job.counters->slot[sgm].cand_count;  // values exist below this index
+            if (v0 >= end) continue;
+            int64_t x[2 * PAIRS];
+            load_tile_from(job.cand, ZBRA_ELEM_I64, v0, end, 0, x);
+#pragma unroll
+            for (int e = 0; e < 2 * PAIRS; ++e) {
+                const uint64_t i = v0 + (e >> 1) * THREADS * 2 + threadIdx.x * 2 + (e & 1);
+                if (i < end) hist_key(lh, ((uint64_t)x[e] ^ SIGN) - base, pass, shift, prefix, last, above);
+            }
         }
-        __syncthreads();
-    });
+    }
+    __syncthreads();
+    uint32_t *gh = hist + (size_t)a * BINS;
+    for (uint32_t b = threadIdx.x; b < BINS; b += THREADS) {
+        const uint32_t c = lh[b];
+        if (c) atomicAdd(&gh[b], c);
+    }
+    if (last && pass > 0) {
+        above = wave_min_u64(above);
+        if ((threadIdx.x & 63) == 0 && above != ~0ull)
+            atomicMin((unsigned long long *)&jobs[a].next_above, (unsigned long long)above);
+    }
 }
 
 // One workgroup per array: finds the bin that holds rank k, descends, and on the last pass
@@ -325,8 +626,8 @@ __global__ __launch_bounds__(THREADS) void enc_select_kernel(EncodeJob *__restri
                 if (next_bin < BINS) key_b = pass == 0 ? (uint64_t)next_bin : (high << DIGIT_BITS) | next_bin;
                 else key_b = job.next_above;
             }
-            const int64_t va = (int64_t)((key_a + job.min_b) ^ SIGN);
-            const int64_t vb = (int64_t)((key_b + job.min_b) ^ SIGN);
+            const int64_t va = (int64_t)((key_a + job.key_base) ^ SIGN);
+            const int64_t vb = (int64_t)((key_b + job.key_base) ^ SIGN);
             set_midpoint(job, va, vb, even);
         }
     }
