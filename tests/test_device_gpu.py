@@ -192,3 +192,43 @@ def test_full_size_roundtrip_properties(env):
     assert pk[0] == 12
     head = out[13:13 + m * 12 // 8].cpu().numpy().tobytes()
     assert head == pk[1:1 + m * 12 // 8]
+
+
+def test_decode_garbage_never_reads_or_writes_outside(env):
+    """Random and adversarial header bytes: whatever the 13 header bytes claim, the decoder only
+    reads inside [data, data + len) and writes inside out[0:count].  Every case is checked against
+    the oracle's verdict (status, and values when it accepts)."""
+    torch, device, oc, L = env
+    rng = np.random.default_rng(4242)
+    guard = 64
+    cases = []
+    for _ in range(200):
+        ln = int(rng.integers(0, 300))
+        data = bytearray(rng.integers(0, 256, ln, dtype=np.uint8).tobytes())
+        if ln >= 13 and rng.random() < 0.8:  # plausible packed_len and width so that many cases decode
+            pl = int(rng.integers(0, ln - 11))
+            data[8:12] = pl.to_bytes(4, "little")
+            data[12] = int(rng.choice([0, 1, 2, 7, 12, 31, 32, 33, 64, 65, 200, 255]))
+        cases.append((bytes(data), int(rng.integers(0, 400))))
+    # packed_len far beyond the buffer, and maximal
+    cases.append((bytes(8) + (0xFFFFFFFF).to_bytes(4, "little") + bytes([12]) + bytes(50), 10))
+    cases.append((bytes(8) + (51).to_bytes(4, "little") + bytes([31]) + bytes(50), 1 << 20))   # count >> payload
+    cases.append((bytes(8) + (51).to_bytes(4, "little") + bytes([64]) + bytes(50), 1000))      # raw, mostly missing
+    for data, count in cases:
+        rc, expect = oc.decompress_int_array(data, count)
+        d = torch.full((guard + len(data) + guard,), 0x5A, dtype=torch.uint8, device="cuda")
+        if data:
+            d[guard:guard + len(data)] = torch.frombuffer(bytearray(data), dtype=torch.uint8).cuda()
+        out = torch.full((count + 2 * 8,), -77, dtype=torch.int64, device="cuda")
+        res = device.new_results(1, "cuda")
+        device.decode_dev(d[guard:guard + len(data)], count, out[8:8 + count] if count else out[8:8], res, length=len(data))
+        r = device.read_results(res)[0]
+        got = out.cpu().numpy()
+        assert r.status == rc, (data[:16].hex(), len(data), count, r.status, rc)
+        assert (got[:8] == -77).all() and (got[8 + count:] == -77).all(), "wrote outside out[0:count]"
+        if rc == 0:
+            assert r.out_count == expect.size
+            assert np.array_equal(got[8:8 + expect.size], expect), (data[:16].hex(), len(data), count)
+            assert (got[8 + expect.size:8 + count] == -77).all()
+        else:
+            assert (got == -77).all()
