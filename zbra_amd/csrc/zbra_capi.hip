@@ -319,6 +319,82 @@ static int host_check_decode(const uint8_t *data, size_t len, size_t count, size
     return ZBRA_OK;
 }
 
+// Large arrays: the header is readable on the host, so the array is cut into pieces of
+// HOST_PIECE_BYTES of output whose plans the host writes itself (a piece of a constant-width array
+// is an array with the same midpoint and width that starts at a later payload byte).  Piece c+1
+// is uploaded and decoded on the context's stream while piece c travels back on a second one: the
+// two directions of the link work at the same time.
+constexpr size_t HOST_PIECE_BYTES = (size_t)64 << 20;
+
+static int decode_host_pieces(DeviceCtx *ctx, const uint8_t *data, size_t used, size_t count, void *out, uint32_t kind) {
+    const size_t esz = kind == ZBRA_ELEM_I64 ? 8 : 4;
+    const size_t per = HOST_PIECE_BYTES / esz;  // values per piece: a multiple of every tile size
+    const size_t np = (count + per - 1) / per;
+    int64_t mid;
+    uint32_t pl;
+    std::memcpy(&mid, data, 8);
+    std::memcpy(&pl, data + 8, 4);
+    const uint32_t w = data[12];
+    const uint64_t avail = (uint64_t)pl - 1;
+    // first byte of E that piece c needs (piece 0 also carries the header) and one past its last
+    auto first_byte = [&](size_t c) -> size_t {
+        if (c == 0) return 0;
+        const uint64_t v0 = (uint64_t)c * per;
+        const uint64_t o = w == 0 ? 0 : w < 32 ? v0 * w / 8 : v0 * 8;
+        return (size_t)(13 + (o < avail ? o : avail));
+    };
+    auto end_byte = [&](size_t c) -> size_t {
+        const uint64_t v1 = (uint64_t)(c + 1) * per < count ? (uint64_t)(c + 1) * per : count;
+        const uint64_t o = w == 0 ? 0 : w < 32 ? (v1 * w + 7) / 8 : v1 * 8;
+        return (size_t)(13 + (o < avail ? o : avail));
+    };
+    if (!ctx->stream2) ZBRA_HIP_TRY(hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking));
+    for (hipEvent_t &e : ctx->piece_done)
+        if (!e) ZBRA_HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    // plans: 128 B per piece = DecodePlan at +0, tile_start {0, ntiles} at +64
+    Slot *s;
+    ZBRA_TRY(ctx->acquire(np * 128, &s));
+    for (size_t c = 0; c < np; c++) {
+        const uint64_t v0 = (uint64_t)c * per, nv = count - v0 < per ? count - v0 : per;
+        const uint64_t o = w == 0 ? 0 : w < 32 ? v0 * w / 8 : v0 * 8;
+        DecodePlan p;
+        p.payload = (const uint8_t *)ctx->dev_in.ptr + 13 + o;
+        p.out = (char *)ctx->dev_out.ptr + v0 * esz;
+        p.count = nv; p.midpoint = mid; p.avail = o < avail ? avail - o : 0; p.width = w; p.kind = kind;
+        std::memcpy((char *)s->host + c * 128, &p, sizeof(p));
+        const uint64_t ts[2] = {0, decode_tiles_of(nv, kind)};
+        std::memcpy((char *)s->host + c * 128 + 64, ts, sizeof(ts));
+    }
+    hipStream_t up = ctx->stream, down = ctx->stream2;
+    size_t submitted = 0;  // pieces uploaded and launched so far
+    auto submit = [&]() -> int {
+        const size_t c = submitted;
+        const size_t b0 = first_byte(c), b1 = end_byte(c);
+        if (b1 > b0) ZBRA_TRY(ctx->pipe_up.to_device((char *)ctx->dev_in.ptr + b0, data + b0, b1 - b0, up));
+        const uint64_t v0 = (uint64_t)c * per, nv = count - v0 < per ? count - v0 : per;
+        launch_decode(up, (const DecodePlan *)((char *)s->dev + c * 128), (const uint64_t *)((char *)s->dev + c * 128 + 64), nullptr, 1u,
+                      decode_tiles_of(nv, kind));
+        ZBRA_HIP_TRY(hipGetLastError());
+        ZBRA_HIP_TRY(hipEventRecord(ctx->piece_done[c % 4], up));
+        submitted++;
+        return ZBRA_OK;
+    };
+    int st = hip_status(hipMemcpyAsync(s->dev, s->host, np * 128, hipMemcpyHostToDevice, up));
+    size_t waited = 0;  // pieces the way back has been told to wait for
+    if (st == ZBRA_OK)
+        st = ctx->pipe.to_host(out, ctx->dev_out.ptr, count * esz, down, [&](size_t last_byte) -> int {
+            // the chunk ending at last_byte needs pieces up to this one; keep one more in flight
+            const size_t need = (last_byte + HOST_PIECE_BYTES - 1) / HOST_PIECE_BYTES;
+            while (submitted < np && submitted < need + 1) ZBRA_TRY(submit());
+            for (; waited < need; waited++) ZBRA_HIP_TRY(hipStreamWaitEvent(down, ctx->piece_done[waited % 4], 0));
+            return ZBRA_OK;
+        });
+    // nothing of this call may still run when the arenas are handed to the next one
+    const int st_up = hip_status(hipStreamSynchronize(up)), st_down = hip_status(hipStreamSynchronize(down));
+    const int st_rel = ctx->release(s, up);
+    return st != ZBRA_OK ? st : st_up != ZBRA_OK ? st_up : st_down != ZBRA_OK ? st_down : st_rel;
+}
+
 static int decode_host(const uint8_t *data, size_t len, size_t count, void *out, uint32_t kind, size_t *out_count) {
     if (!out_count || (len && !data)) return ZBRA_ERR_INVALID_ARG;
     if (count > MAX_COUNT) return ZBRA_ERR_INVALID_ARG;
@@ -334,12 +410,12 @@ static int decode_host(const uint8_t *data, size_t len, size_t count, void *out,
     const size_t used = 12 + (size_t)(*(const uint32_t *)(data + 8));  // bytes after 12 + packed_len are ignored
     ZBRA_TRY(DeviceCtx::grow_dev(ctx->dev_in, used + 16));
     ZBRA_TRY(DeviceCtx::grow_dev(ctx->dev_out, count * esz));
-    ZBRA_HIP_TRY(hipMemcpyAsync(ctx->dev_in.ptr, data, used, hipMemcpyHostToDevice, ctx->stream));
+    if (count * esz >= 2 * HOST_PIECE_BYTES && HostPipe::enabled()) return decode_host_pieces(ctx, data, used, count, out, kind);
+    ZBRA_TRY(ctx->pipe.to_device(ctx->dev_in.ptr, data, used, ctx->stream));
     zbra_array_desc d;
     d.data = (const uint8_t *)ctx->dev_in.ptr; d.len = used; d.count = count; d.out = ctx->dev_out.ptr; d.kind = kind; d.reserved = 0;
     ZBRA_TRY(decode_batch_dev(ctx, &d, 1, nullptr, ctx->stream));
-    ZBRA_HIP_TRY(hipMemcpyAsync(out, ctx->dev_out.ptr, count * esz, hipMemcpyDeviceToHost, ctx->stream));
-    ZBRA_HIP_TRY(hipStreamSynchronize(ctx->stream));
+    ZBRA_TRY(ctx->pipe.to_host(out, ctx->dev_out.ptr, count * esz, ctx->stream));
     return ZBRA_OK;
 }
 
@@ -356,7 +432,7 @@ static int encode_host(const void *values, size_t n, uint32_t kind, uint8_t *out
     ZBRA_TRY(DeviceCtx::grow_dev(ctx->dev_in, n * esz));
     ZBRA_TRY(DeviceCtx::grow_dev(ctx->dev_out, bound + 16));
     ZBRA_TRY(DeviceCtx::grow_dev(ctx->dev_tmp, sizeof(zbra_dev_result)));
-    ZBRA_HIP_TRY(hipMemcpyAsync(ctx->dev_in.ptr, values, n * esz, hipMemcpyHostToDevice, ctx->stream));
+    ZBRA_TRY(ctx->pipe.to_device(ctx->dev_in.ptr, values, n * esz, ctx->stream));
     EncodeItem it{ctx->dev_in.ptr, n, kind, (uint8_t *)ctx->dev_out.ptr, bound};
     ZBRA_TRY(encode_batch_dev(ctx, &it, 1, (zbra_dev_result *)ctx->dev_tmp.ptr, ctx->stream));
     zbra_dev_result r;
@@ -364,7 +440,7 @@ static int encode_host(const void *values, size_t n, uint32_t kind, uint8_t *out
     ZBRA_HIP_TRY(hipStreamSynchronize(ctx->stream));
     if (r.status != ZBRA_OK) return (int)r.status;
     if (r.out_count > cap || !out) return ZBRA_ERR_CAPACITY;
-    ZBRA_HIP_TRY(hipMemcpy(out, ctx->dev_out.ptr, r.out_count, hipMemcpyDeviceToHost));
+    ZBRA_TRY(ctx->pipe.to_host(out, ctx->dev_out.ptr, r.out_count, ctx->stream));
     *out_len = r.out_count;
     return ZBRA_OK;
 }
@@ -379,11 +455,10 @@ static int stage_host(const void *in, size_t in_bytes, void *out, size_t out_byt
     std::lock_guard<std::mutex> g(ctx->host_mu);
     ZBRA_TRY(DeviceCtx::grow_dev(ctx->dev_in, in_bytes));
     ZBRA_TRY(DeviceCtx::grow_dev(ctx->dev_out, out_bytes));
-    ZBRA_HIP_TRY(hipMemcpyAsync(ctx->dev_in.ptr, in, in_bytes, hipMemcpyHostToDevice, ctx->stream));
+    ZBRA_TRY(ctx->pipe.to_device(ctx->dev_in.ptr, in, in_bytes, ctx->stream));
     launch(ctx->dev_in.ptr, ctx->dev_out.ptr, ctx->stream);
     ZBRA_HIP_TRY(hipGetLastError());
-    ZBRA_HIP_TRY(hipMemcpyAsync(out, ctx->dev_out.ptr, out_bytes, hipMemcpyDeviceToHost, ctx->stream));
-    ZBRA_HIP_TRY(hipStreamSynchronize(ctx->stream));
+    ZBRA_TRY(ctx->pipe.to_host(out, ctx->dev_out.ptr, out_bytes, ctx->stream));
     return ZBRA_OK;
 }
 
@@ -460,7 +535,7 @@ int zbra_hip_frame_of_reference_encode(const int64_t *values, size_t n, int64_t 
     ZBRA_TRY(DeviceCtx::grow_dev(ctx->dev_in, n * 8));
     ZBRA_TRY(DeviceCtx::grow_dev(ctx->dev_out, n * 8));
     ZBRA_TRY(DeviceCtx::grow_dev(ctx->dev_tmp, sizeof(zbra_dev_result)));
-    ZBRA_HIP_TRY(hipMemcpyAsync(ctx->dev_in.ptr, values, n * 8, hipMemcpyHostToDevice, ctx->stream));
+    ZBRA_TRY(ctx->pipe.to_device(ctx->dev_in.ptr, values, n * 8, ctx->stream));
     EncodeItem it{ctx->dev_in.ptr, n, ZBRA_ELEM_I64, nullptr, 0};
     ZBRA_TRY(encode_batch_dev(ctx, &it, 1, (zbra_dev_result *)ctx->dev_tmp.ptr, ctx->stream, ENCODE_MEDIAN_ONLY));
     const unsigned grid = grid_for((n + THREADS * 2 - 1) / (THREADS * 2), STREAM_GRID_CAP);
@@ -469,8 +544,7 @@ int zbra_hip_frame_of_reference_encode(const int64_t *values, size_t n, int64_t 
     ZBRA_HIP_TRY(hipGetLastError());
     zbra_dev_result r;
     ZBRA_HIP_TRY(hipMemcpyAsync(&r, ctx->dev_tmp.ptr, sizeof(r), hipMemcpyDeviceToHost, ctx->stream));
-    ZBRA_HIP_TRY(hipMemcpyAsync(deltas, ctx->dev_out.ptr, n * 8, hipMemcpyDeviceToHost, ctx->stream));
-    ZBRA_HIP_TRY(hipStreamSynchronize(ctx->stream));
+    ZBRA_TRY(ctx->pipe.to_host(deltas, ctx->dev_out.ptr, n * 8, ctx->stream));
     *midpoint = r.midpoint;
     return ZBRA_OK;
 }
@@ -511,7 +585,7 @@ int zbra_hip_bp64_pack(const uint64_t *values, size_t n, uint8_t *out, size_t ca
     ZBRA_TRY(DeviceCtx::grow_dev(ctx->dev_in, n * 8));
     ZBRA_TRY(DeviceCtx::grow_dev(ctx->dev_out, 12 + bound + 32));
     ZBRA_TRY(DeviceCtx::grow_dev(ctx->dev_tmp, sizeof(zbra_dev_result)));
-    ZBRA_HIP_TRY(hipMemcpyAsync(ctx->dev_in.ptr, values, n * 8, hipMemcpyHostToDevice, ctx->stream));
+    ZBRA_TRY(ctx->pipe.to_device(ctx->dev_in.ptr, values, n * 8, ctx->stream));
     // The stream is built by the encode pipeline with values taken as they are; its E layout puts
     // the width byte at +12, so `packed` is E without the 12 header bytes.
     EncodeItem it{ctx->dev_in.ptr, n, KIND_U64_PLAIN, (uint8_t *)ctx->dev_out.ptr, 12 + bound};
@@ -522,7 +596,7 @@ int zbra_hip_bp64_pack(const uint64_t *values, size_t n, uint8_t *out, size_t ca
     if (r.status != ZBRA_OK) return (int)r.status;
     const size_t len = (size_t)r.packed_len;
     if (len > cap || !out) return ZBRA_ERR_CAPACITY;
-    ZBRA_HIP_TRY(hipMemcpy(out, (uint8_t *)ctx->dev_out.ptr + 12, len, hipMemcpyDeviceToHost));
+    ZBRA_TRY(ctx->pipe.to_host(out, (uint8_t *)ctx->dev_out.ptr + 12, len, ctx->stream));
     *out_len = len;
     return ZBRA_OK;
 }
@@ -541,7 +615,7 @@ int zbra_hip_bp64_unpack(const uint8_t *packed, size_t packed_len, size_t count,
     std::lock_guard<std::mutex> g(ctx->host_mu);
     ZBRA_TRY(DeviceCtx::grow_dev(ctx->dev_in, packed_len + 32));
     ZBRA_TRY(DeviceCtx::grow_dev(ctx->dev_out, count * 8));
-    ZBRA_HIP_TRY(hipMemcpyAsync(ctx->dev_in.ptr, packed, packed_len, hipMemcpyHostToDevice, ctx->stream));
+    ZBRA_TRY(ctx->pipe.to_device(ctx->dev_in.ptr, packed, packed_len, ctx->stream));
     ZBRA_TRY(DeviceCtx::grow_dev(ctx->dev_tmp, 256));
     const uint64_t ntiles = decode_tiles_of(count, KIND_U64_PLAIN);
     DecodePlan *plan = (DecodePlan *)ctx->dev_tmp.ptr;
@@ -550,8 +624,7 @@ int zbra_hip_bp64_unpack(const uint8_t *packed, size_t packed_len, size_t count,
                        (uint64_t)packed_len, (uint64_t)count, ctx->dev_out.ptr, ntiles, plan, tile_start);
     launch_decode(ctx->stream, plan, tile_start, nullptr, 1u, ntiles);
     ZBRA_HIP_TRY(hipGetLastError());
-    ZBRA_HIP_TRY(hipMemcpyAsync(out, ctx->dev_out.ptr, count * 8, hipMemcpyDeviceToHost, ctx->stream));
-    ZBRA_HIP_TRY(hipStreamSynchronize(ctx->stream));
+    ZBRA_TRY(ctx->pipe.to_host(out, ctx->dev_out.ptr, count * 8, ctx->stream));
     *out_count = count;
     return ZBRA_OK;
 }
@@ -621,63 +694,83 @@ int zbra_hip_file_decode(const uint8_t *image, size_t len, const zbra_file_array
     ZBRA_TRY(current_ctx(&ctx));
     std::lock_guard<std::mutex> g(ctx->host_mu);
     ZBRA_TRY(ctx->ensure_file_lanes());
-    // Groups of consecutive arrays: bounded image span and bounded output, so that the copies of
-    // one group overlap the kernels of the next on the other lane.
+    // Groups of consecutive arrays with a bounded image span and a bounded output.  Group k+1 is
+    // uploaded and decoded on the other lane while the values of group k travel back, so the two
+    // directions of the link and the kernels overlap.
     constexpr size_t MAX_SPAN = (size_t)64 << 20, MAX_OUT = (size_t)512 << 20, MAX_ARRAYS = 4096;
-    std::vector<zbra_dev_result> results(n);
-    std::vector<zbra_array_desc> descs;
-    size_t i = 0, lane_idx = 0;
-    int first_err = ZBRA_OK;
-    while (i < n) {
+    struct Group { size_t first, end, lo, hi, out_bytes; };
+    std::vector<Group> groups;
+    for (size_t i = 0; i < n;) {
         size_t j = i, out_bytes = 0;
         const size_t lo = arrays[i].offset;
         size_t hi = lo;
         while (j < n && j - i < MAX_ARRAYS) {
-            const size_t esz = arrays[j].kind == ZBRA_ELEM_I64 ? 8 : 4;
-            const size_t ob = (arrays[j].count * esz + 15) / 16 * 16;
+            const size_t ob = (arrays[j].count * (arrays[j].kind == ZBRA_ELEM_I64 ? 8 : 4) + 15) / 16 * 16;
             const size_t h = arrays[j].offset + arrays[j].len;
             if (j > i && (h - lo > MAX_SPAN || out_bytes + ob > MAX_OUT)) break;
             out_bytes += ob;
             hi = h;
             j++;
         }
-        FileLane &lane = ctx->file_lanes[lane_idx];
-        lane_idx ^= 1;
-        // the lane's buffers are reused: everything enqueued on it earlier must have run before
-        // they may be reallocated (same-size reuse is ordered by the stream itself)
-        const size_t span = hi - lo, ng = j - i;
-        if (lane.img.cap < span + 16 || lane.out.cap < out_bytes + 16 || lane.res.cap < ng * sizeof(zbra_dev_result)) {
-            ZBRA_HIP_TRY(hipStreamSynchronize(lane.stream));
-            ZBRA_TRY(DeviceCtx::grow_dev(lane.img, span + 16));
-            ZBRA_TRY(DeviceCtx::grow_dev(lane.out, out_bytes + 16));
-            ZBRA_TRY(DeviceCtx::grow_dev(lane.res, ng * sizeof(zbra_dev_result)));
-        }
-        if (span) ZBRA_HIP_TRY(hipMemcpyAsync(lane.img.ptr, image + lo, span, hipMemcpyHostToDevice, lane.stream));
+        groups.push_back({i, j, lo, hi, out_bytes});
+        i = j;
+    }
+    std::vector<zbra_dev_result> results(n);
+    std::vector<zbra_array_desc> descs;
+    std::vector<HostPipe::Segment> segs;
+    size_t submitted = 0;
+    auto submit = [&]() -> int {  // upload + decode of the next group, on its lane
+        const Group &gr = groups[submitted];
+        FileLane &lane = ctx->file_lanes[submitted & 1];
+        const size_t span = gr.hi - gr.lo, ng = gr.end - gr.first;
+        // the lane's previous group has been copied back completely (its to_host returned), so
+        // its buffers may be reallocated
+        ZBRA_TRY(DeviceCtx::grow_dev(lane.img, span + 16));
+        ZBRA_TRY(DeviceCtx::grow_dev(lane.out, gr.out_bytes + 16));
+        ZBRA_TRY(DeviceCtx::grow_dev(lane.res, ng * sizeof(zbra_dev_result)));
+        ZBRA_TRY(ctx->pipe_up.to_device(lane.img.ptr, image + gr.lo, span, lane.stream));
         descs.resize(ng);
         size_t o = 0;
         for (size_t k = 0; k < ng; k++) {
-            const zbra_file_array &a = arrays[i + k];
-            descs[k].data = (const uint8_t *)lane.img.ptr + (a.offset - lo);
+            const zbra_file_array &a = arrays[gr.first + k];
+            descs[k].data = (const uint8_t *)lane.img.ptr + (a.offset - gr.lo);
             descs[k].len = a.len; descs[k].count = a.count; descs[k].out = (char *)lane.out.ptr + o;
             descs[k].kind = a.kind; descs[k].reserved = 0;
             o += (a.count * (a.kind == ZBRA_ELEM_I64 ? 8 : 4) + 15) / 16 * 16;
         }
         ZBRA_TRY(decode_batch_dev(ctx, descs.data(), ng, (zbra_dev_result *)lane.res.ptr, lane.stream));
-        ZBRA_HIP_TRY(hipMemcpyAsync(&results[i], lane.res.ptr, ng * sizeof(zbra_dev_result), hipMemcpyDeviceToHost, lane.stream));
+        ZBRA_HIP_TRY(hipMemcpyAsync(&results[gr.first], lane.res.ptr, ng * sizeof(zbra_dev_result), hipMemcpyDeviceToHost, lane.stream));
+        submitted++;
+        return ZBRA_OK;
+    };
+    int st = ZBRA_OK;
+    for (size_t gi = 0; gi < groups.size() && st == ZBRA_OK; gi++) {
+        if (submitted == gi) st = submit();
+        if (st != ZBRA_OK) break;
+        const Group &gr = groups[gi];
+        FileLane &lane = ctx->file_lanes[gi & 1];
         // The number of values an array produces is known from its header, which the host can
-        // read in the image: copy back exactly that (0 for empty / rejected arrays).
-        for (size_t k = 0; k < ng; k++) {
-            const zbra_file_array &a = arrays[i + k];
+        // read in the image: copy back exactly that (nothing for empty / rejected arrays).
+        segs.clear();
+        size_t o = 0;
+        for (size_t k = gr.first; k < gr.end; k++) {
+            const zbra_file_array &a = arrays[k];
+            const size_t esz = a.kind == ZBRA_ELEM_I64 ? 8 : 4;
             size_t produced = 0;
-            const int st = host_check_decode(image + a.offset, a.len, a.count, &produced);
-            if (st == ZBRA_OK && produced)
-                ZBRA_HIP_TRY(hipMemcpyAsync(outs[i + k], descs[k].out, produced * (a.kind == ZBRA_ELEM_I64 ? 8 : 4),
-                                            hipMemcpyDeviceToHost, lane.stream));
+            if (host_check_decode(image + a.offset, a.len, a.count, &produced) == ZBRA_OK && produced)
+                segs.push_back({o, outs[k], produced * esz});
+            o += (a.count * esz + 15) / 16 * 16;
         }
-        i = j;
+        st = ctx->pipe.to_host_segments(segs.data(), segs.size(), lane.out.ptr, gr.out_bytes, lane.stream, [&](size_t) -> int {
+            if (submitted == gi + 1 && submitted < groups.size()) return submit();
+            return ZBRA_OK;
+        });
     }
-    ZBRA_HIP_TRY(hipStreamSynchronize(ctx->file_lanes[0].stream));
-    ZBRA_HIP_TRY(hipStreamSynchronize(ctx->file_lanes[1].stream));
+    const int st0 = hip_status(hipStreamSynchronize(ctx->file_lanes[0].stream));
+    const int st1 = hip_status(hipStreamSynchronize(ctx->file_lanes[1].stream));
+    if (st == ZBRA_OK) st = st0 != ZBRA_OK ? st0 : st1;
+    if (st != ZBRA_OK) return st;
+    int first_err = ZBRA_OK;
     for (size_t k = 0; k < n; k++) {
         if (statuses) statuses[k] = (int)results[k].status;
         if (results[k].status != ZBRA_OK && first_err == ZBRA_OK) first_err = (int)results[k].status;

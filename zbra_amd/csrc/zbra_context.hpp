@@ -24,6 +24,12 @@ inline int hip_status(hipError_t e) { return e == hipSuccess ? ZBRA_OK : ZBRA_ER
         if (_s != ZBRA_OK) return _s;  \
     } while (0)
 
+}  // namespace zbra
+
+#include "zbra_hostpipe.hpp"
+
+namespace zbra {
+
 // A pair of equally sized buffers (pinned host + device) lent to ONE enqueued call.  The host
 // side may be rewritten only after everything the previous borrower enqueued has run, which the
 // slot's event says.
@@ -62,8 +68,11 @@ struct DeviceCtx {
     std::vector<Slot *> slots;  // pointers stay valid while the vector grows
     std::mutex host_mu;         // serialises host-pointer calls: they share the arenas and the stream
     hipStream_t stream = nullptr;
+    hipStream_t stream2 = nullptr;            // the way back of a piecewise host decode
+    hipEvent_t piece_done[4] = {nullptr, nullptr, nullptr, nullptr};
     Arena dev_in, dev_out, dev_tmp;
-    Arena pin_in, pin_out;
+    HostPipe pipe;              // pageable host memory <-> device, under host_mu
+    HostPipe pipe_up;           // uploads issued while `pipe` is busy with the way back (piecewise decode)
 
     // scratch_bytes of device-only memory come with the slot (grown while the slot is idle).
     int acquire(size_t bytes, Slot **out, size_t scratch_bytes = 0) {
