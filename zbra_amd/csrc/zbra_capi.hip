@@ -694,81 +694,93 @@ int zbra_hip_file_decode(const uint8_t *image, size_t len, const zbra_file_array
     ZBRA_TRY(current_ctx(&ctx));
     std::lock_guard<std::mutex> g(ctx->host_mu);
     ZBRA_TRY(ctx->ensure_file_lanes());
-    // Groups of consecutive arrays with a bounded image span and a bounded output.  Group k+1 is
-    // uploaded and decoded on the other lane while the values of group k travel back, so the two
-    // directions of the link and the kernels overlap.
-    constexpr size_t MAX_SPAN = (size_t)64 << 20, MAX_OUT = (size_t)512 << 20, MAX_ARRAYS = 4096;
-    struct Group { size_t first, end, lo, hi, out_bytes; };
-    std::vector<Group> groups;
-    for (size_t i = 0; i < n;) {
-        size_t j = i, out_bytes = 0;
-        const size_t lo = arrays[i].offset;
-        size_t hi = lo;
-        while (j < n && j - i < MAX_ARRAYS) {
-            const size_t ob = (arrays[j].count * (arrays[j].kind == ZBRA_ELEM_I64 ? 8 : 4) + 15) / 16 * 16;
-            const size_t h = arrays[j].offset + arrays[j].len;
-            if (j > i && (h - lo > MAX_SPAN || out_bytes + ob > MAX_OUT)) break;
-            out_bytes += ob;
-            hi = h;
-            j++;
-        }
-        groups.push_back({i, j, lo, hi, out_bytes});
-        i = j;
-    }
-    std::vector<zbra_dev_result> results(n);
+    if (!ctx->stream2) ZBRA_HIP_TRY(hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking));
+    for (hipEvent_t &e : ctx->piece_done)
+        if (!e) ZBRA_HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    // The decoded values of up to MAX_OUT bytes of arrays ("a round") share one device buffer that
+    // a single pipelined copy takes back to the caller's arrays.  Inside a round, groups of
+    // consecutive arrays (bounded image span) are uploaded and decoded on two alternating lanes
+    // just ahead of the copy: upload, kernels and the way back overlap, and the copy never drains
+    // between groups.
+    constexpr size_t MAX_SPAN = (size_t)16 << 20, MAX_OUT = (size_t)4 << 30, MAX_ARRAYS = 4096;
+    struct Group { size_t first, end, lo, hi, out_off, out_end; };
+    // status words come back into pinned memory: a copy into pageable memory would block the
+    // host until the group's kernels have run, and the host has the copy back to keep fed
+    ZBRA_TRY(DeviceCtx::grow_pinned(ctx->pin_res, n * sizeof(zbra_dev_result)));
+    zbra_dev_result *results = (zbra_dev_result *)ctx->pin_res.ptr;
     std::vector<zbra_array_desc> descs;
     std::vector<HostPipe::Segment> segs;
-    size_t submitted = 0;
-    auto submit = [&]() -> int {  // upload + decode of the next group, on its lane
-        const Group &gr = groups[submitted];
-        FileLane &lane = ctx->file_lanes[submitted & 1];
-        const size_t span = gr.hi - gr.lo, ng = gr.end - gr.first;
-        // the lane's previous group has been copied back completely (its to_host returned), so
-        // its buffers may be reallocated
-        ZBRA_TRY(DeviceCtx::grow_dev(lane.img, span + 16));
-        ZBRA_TRY(DeviceCtx::grow_dev(lane.out, gr.out_bytes + 16));
-        ZBRA_TRY(DeviceCtx::grow_dev(lane.res, ng * sizeof(zbra_dev_result)));
-        ZBRA_TRY(ctx->pipe_up.to_device(lane.img.ptr, image + gr.lo, span, lane.stream));
-        descs.resize(ng);
-        size_t o = 0;
-        for (size_t k = 0; k < ng; k++) {
-            const zbra_file_array &a = arrays[gr.first + k];
-            descs[k].data = (const uint8_t *)lane.img.ptr + (a.offset - gr.lo);
-            descs[k].len = a.len; descs[k].count = a.count; descs[k].out = (char *)lane.out.ptr + o;
-            descs[k].kind = a.kind; descs[k].reserved = 0;
-            o += (a.count * (a.kind == ZBRA_ELEM_I64 ? 8 : 4) + 15) / 16 * 16;
-        }
-        ZBRA_TRY(decode_batch_dev(ctx, descs.data(), ng, (zbra_dev_result *)lane.res.ptr, lane.stream));
-        ZBRA_HIP_TRY(hipMemcpyAsync(&results[gr.first], lane.res.ptr, ng * sizeof(zbra_dev_result), hipMemcpyDeviceToHost, lane.stream));
-        submitted++;
-        return ZBRA_OK;
-    };
+    std::vector<Group> groups;
+    std::vector<size_t> out_off(n);
+    auto padded = [&](size_t k) { return (size_t)((arrays[k].count * (arrays[k].kind == ZBRA_ELEM_I64 ? 8 : 4) + 15) / 16 * 16); };
     int st = ZBRA_OK;
-    for (size_t gi = 0; gi < groups.size() && st == ZBRA_OK; gi++) {
-        if (submitted == gi) st = submit();
-        if (st != ZBRA_OK) break;
-        const Group &gr = groups[gi];
-        FileLane &lane = ctx->file_lanes[gi & 1];
-        // The number of values an array produces is known from its header, which the host can
-        // read in the image: copy back exactly that (nothing for empty / rejected arrays).
-        segs.clear();
-        size_t o = 0;
-        for (size_t k = gr.first; k < gr.end; k++) {
-            const zbra_file_array &a = arrays[k];
-            const size_t esz = a.kind == ZBRA_ELEM_I64 ? 8 : 4;
-            size_t produced = 0;
-            if (host_check_decode(image + a.offset, a.len, a.count, &produced) == ZBRA_OK && produced)
-                segs.push_back({o, outs[k], produced * esz});
-            o += (a.count * esz + 15) / 16 * 16;
+    for (size_t r0 = 0; r0 < n && st == ZBRA_OK;) {
+        // ---- one round: arrays [r0, r1) ----
+        size_t r1 = r0, total = 0;
+        groups.clear();
+        while (r1 < n && (r1 == r0 || total + padded(r1) <= MAX_OUT)) {
+            Group gr{r1, r1, arrays[r1].offset, arrays[r1].offset, total, total};
+            while (r1 < n && r1 - gr.first < MAX_ARRAYS) {
+                const size_t h = arrays[r1].offset + arrays[r1].len, ob = padded(r1);
+                if (r1 > gr.first && (h - gr.lo > MAX_SPAN || total + ob > MAX_OUT)) break;
+                out_off[r1] = total;
+                total += ob;
+                gr.hi = h;
+                r1++;
+            }
+            gr.end = r1;
+            gr.out_end = total;
+            groups.push_back(gr);
         }
-        st = ctx->pipe.to_host_segments(segs.data(), segs.size(), lane.out.ptr, gr.out_bytes, lane.stream, [&](size_t) -> int {
-            if (submitted == gi + 1 && submitted < groups.size()) return submit();
+        ZBRA_TRY(DeviceCtx::grow_dev(ctx->dev_out, total + 16));
+        // what goes back: exactly the values each array produces, known from its header, which the
+        // host can read in the image (nothing for empty / rejected arrays)
+        segs.clear();
+        for (size_t k = r0; k < r1; k++) {
+            size_t produced = 0;
+            if (host_check_decode(image + arrays[k].offset, arrays[k].len, arrays[k].count, &produced) == ZBRA_OK && produced)
+                segs.push_back({out_off[k], outs[k], produced * (arrays[k].kind == ZBRA_ELEM_I64 ? 8 : 4)});
+        }
+        size_t submitted = 0, waited = 0;
+        auto submit = [&]() -> int {  // upload + decode of the next group, on its lane
+            const Group &gr = groups[submitted];
+            FileLane &lane = ctx->file_lanes[submitted & 1];
+            const size_t span = gr.hi - gr.lo, ng = gr.end - gr.first;
+            if (lane.img.cap < span + 16 || lane.res.cap < ng * sizeof(zbra_dev_result)) {
+                ZBRA_HIP_TRY(hipStreamSynchronize(lane.stream));  // a kernel may still read the old buffers
+                ZBRA_TRY(DeviceCtx::grow_dev(lane.img, span + 16));
+                ZBRA_TRY(DeviceCtx::grow_dev(lane.res, ng * sizeof(zbra_dev_result)));
+            }
+            ZBRA_TRY(ctx->pipe_up.to_device(lane.img.ptr, image + gr.lo, span, lane.stream));
+            descs.resize(ng);
+            for (size_t k = 0; k < ng; k++) {
+                const zbra_file_array &a = arrays[gr.first + k];
+                descs[k].data = (const uint8_t *)lane.img.ptr + (a.offset - gr.lo);
+                descs[k].len = a.len; descs[k].count = a.count; descs[k].out = (char *)ctx->dev_out.ptr + out_off[gr.first + k];
+                descs[k].kind = a.kind; descs[k].reserved = 0;
+            }
+            ZBRA_TRY(decode_batch_dev(ctx, descs.data(), ng, (zbra_dev_result *)lane.res.ptr, lane.stream));
+            ZBRA_HIP_TRY(hipMemcpyAsync(&results[gr.first], lane.res.ptr, ng * sizeof(zbra_dev_result), hipMemcpyDeviceToHost, lane.stream));
+            ZBRA_HIP_TRY(hipEventRecord(ctx->piece_done[submitted % 4], lane.stream));
+            submitted++;
+            return ZBRA_OK;
+        };
+        st = ctx->pipe.to_host_segments(segs.data(), segs.size(), ctx->dev_out.ptr, total, ctx->stream2, [&](size_t last_byte) -> int {
+            // groups that produce bytes below last_byte must have been enqueued; keep one more in flight
+            size_t need = waited;
+            while (need < groups.size() && groups[need].out_off < last_byte) need++;
+            while (submitted < groups.size() && submitted < need + 1) ZBRA_TRY(submit());
+            for (; waited < need; waited++) ZBRA_HIP_TRY(hipStreamWaitEvent(ctx->stream2, ctx->piece_done[waited % 4], 0));
             return ZBRA_OK;
         });
+        // groups whose arrays produce nothing are still decoded for their status words
+        while (st == ZBRA_OK && submitted < groups.size()) st = submit();
+        const int st0 = hip_status(hipStreamSynchronize(ctx->file_lanes[0].stream));
+        const int st1 = hip_status(hipStreamSynchronize(ctx->file_lanes[1].stream));
+        const int st2 = hip_status(hipStreamSynchronize(ctx->stream2));
+        if (st == ZBRA_OK) st = st0 != ZBRA_OK ? st0 : st1 != ZBRA_OK ? st1 : st2;
+        r0 = r1;
     }
-    const int st0 = hip_status(hipStreamSynchronize(ctx->file_lanes[0].stream));
-    const int st1 = hip_status(hipStreamSynchronize(ctx->file_lanes[1].stream));
-    if (st == ZBRA_OK) st = st0 != ZBRA_OK ? st0 : st1;
     if (st != ZBRA_OK) return st;
     int first_err = ZBRA_OK;
     for (size_t k = 0; k < n; k++) {

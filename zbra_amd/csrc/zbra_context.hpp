@@ -53,7 +53,7 @@ struct Arena {
 // the group of arrays in flight on it.
 struct FileLane {
     hipStream_t stream = nullptr;
-    Arena img, out, res;
+    Arena img, res;
 };
 
 struct DeviceCtx {
@@ -71,6 +71,7 @@ struct DeviceCtx {
     hipStream_t stream2 = nullptr;            // the way back of a piecewise host decode
     hipEvent_t piece_done[4] = {nullptr, nullptr, nullptr, nullptr};
     Arena dev_in, dev_out, dev_tmp;
+    Arena pin_res;              // pinned: status words of a whole-file decode
     HostPipe pipe;              // pageable host memory <-> device, under host_mu
     HostPipe pipe_up;           // uploads issued while `pipe` is busy with the way back (piecewise decode)
 
