@@ -186,6 +186,22 @@ int zbra_hip_decode_batch_dev(const zbra_array_desc *descs, size_t nd, zbra_dev_
 int zbra_hip_encode_dev(const void *d_values, size_t n, uint32_t kind, uint8_t *d_out, size_t cap,
                         zbra_dev_result *d_result, void *stream);
 
+/* The same for `nd` independent arrays in one submission (Column::write_to encodes the arrays of
+ * a Block one after another, binary.rs:275-356).  `descs` is a HOST array of DEVICE pointers;
+ * d_results receives nd entries (status, width, midpoint, out_count = bytes of E). */
+int zbra_hip_encode_batch_dev(const zbra_encode_desc *descs, size_t nd, zbra_dev_result *d_results, void *stream);
+
+/* write_int_array_compressed / write_u32_array_compressed for `nd` arrays (binary.rs:639-645,
+ * 666-669): array i becomes the frame `u32 count | u32 clen | E`, and the frames are laid out back
+ * to back in d_out in the order of `descs`, as they sit in a file when nothing else is written
+ * between them.  The layout happens on the device once the widths are known: d_offsets receives
+ * nd + 1 words, frame i = [d_offsets[i], d_offsets[i+1]).  descs[i].out and .cap are ignored.
+ * Frames that would pass `cap` are not written and get ZBRA_ERR_CAPACITY in d_results (may be
+ * NULL); cap = sum of 8 + zbra_hip_encode_bound(n_i) always suffices.  An empty array is the
+ * 8-byte frame count = 0, clen = 0. */
+int zbra_hip_encode_frames_dev(const zbra_encode_desc *descs, size_t nd, uint8_t *d_out, size_t cap, uint64_t *d_offsets,
+                               zbra_dev_result *d_results, void *stream);
+
 /* ---- .zbra images ------------------------------------------------------------------------ */
 
 /* Walks a .zbra image the way BinaryFile::read_from does (binary.rs:139-174, 195-199, 240-270,
@@ -205,10 +221,14 @@ int zbra_hip_file_index(const uint8_t *image, size_t len, zbra_file_array *array
 int zbra_hip_file_decode(const uint8_t *image, size_t len, const zbra_file_array *arrays, size_t n, void *const *outs,
                          int *statuses);
 
-/* The same for `nd` independent arrays in one submission (Column::write_to encodes the arrays of
- * a Block one after another, binary.rs:275-356).  `descs` is a HOST array of DEVICE pointers;
- * d_results receives nd entries (status, width, midpoint, out_count = bytes of E). */
-int zbra_hip_encode_batch_dev(const zbra_encode_desc *descs, size_t nd, zbra_dev_result *d_results, void *stream);
+/* The write path's counterpart: int arrays in HOST memory (descs[i].values, .n, .kind; .out and
+ * .cap ignored) become frames `u32 count | u32 clen | E` back to back in the HOST buffer `out`,
+ * which is what Column::write_to emits for each of them (binary.rs:293-347 through :639-669).
+ * offsets receives nd + 1 entries; statuses (may be NULL) one zbra_status per array; the return
+ * value is the first non-OK status.  Uploads, the batched encode and the copy back are pipelined
+ * over rounds of arrays. */
+int zbra_hip_encode_frames(const zbra_encode_desc *descs, size_t nd, uint8_t *out, size_t cap, uint64_t *offsets,
+                           int *statuses);
 
 #ifdef __cplusplus
 }

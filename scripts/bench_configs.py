@@ -46,6 +46,19 @@ def run_batch(cols, label, reps):
     rs = device.read_results(res)
     assert all(r.status == 0 for r in rs)
     lens = [int(r.out_count) for r in rs]
+    # a round trip succeeds with ANY midpoint: check the medians themselves against a sort
+    for i, (c, r) in enumerate(zip(cols, rs)):
+        if c.numel() == 0:
+            continue
+        s, _ = torch.sort(c.to(torch.int64) & 0xFFFFFFFF if c.dtype == torch.int32 else c)
+        m = c.numel()
+        a, b = int(s[(m - 1) // 2]), int(s[m // 2])
+        d = b - a
+        if d >= 1 << 63:
+            d -= 1 << 64                                   # b.wrapping_sub(a)
+        want = a + (d // 2 if d >= 0 else -((-d) // 2))    # truncating division
+        want = (want + (1 << 63)) % (1 << 64) - (1 << 63)  # a.wrapping_add(..)
+        assert r.midpoint == want, (label, i, r.midpoint, want)
     outs = [torch.empty_like(c) for c in cols]
     ddesc = device.make_descs([(enc.data_ptr() + o, ln, c.numel(), out.data_ptr(), k)
                                for c, o, ln, out, k in zip(cols, offs, lens, outs, kinds)])

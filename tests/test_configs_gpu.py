@@ -92,3 +92,37 @@ def test_config4_enum_blocks_reduced(env):
             cols += [a, bcol]
     widths = _batch_roundtrip_vs_oracle(env, cols)
     assert 4 in widths  # tags {0,1,2,7} around the median
+
+
+def test_batch_encode_medians_at_scale(env):
+    """A round trip succeeds with any midpoint, so at sizes beyond the oracle's reach the medians
+    are checked against a device sort.  The mix is the one that exposes a workgroup whose lanes
+    disagree about flushing its staged candidates: two-valued tag arrays (their workgroups run at
+    another pace) between wide-range arrays that take the candidate-list route."""
+    torch, device, _, _, _, L = env
+    dev = torch.device("cuda", 0)
+    g = torch.Generator(device=dev)
+    g.manual_seed(11)
+    n = 1 << 22
+    cols = []
+    for b in range(24):
+        tags = torch.randint(0, 2, (n,), dtype=torch.int64, device=dev, generator=g)
+        cols.append(tags.to(torch.int32))
+        cols.append(torch.randint(-(1 << 24), 1 << 24, (n - 1000 - 37 * b,), dtype=torch.int64, device=dev, generator=g))
+    outs = [torch.empty(device.encode_bound(c.numel()), dtype=torch.uint8, device=dev) for c in cols]
+    descs = device.make_encode_descs([(c.data_ptr(), c.numel(), o.data_ptr(), o.numel(),
+                                       L.ELEM_U32 if c.dtype == torch.int32 else L.ELEM_I64) for c, o in zip(cols, outs)])
+    want = []
+    for c in cols:
+        s, _ = torch.sort(c.to(torch.int64))
+        m = c.numel()
+        a, b = int(s[(m - 1) // 2]), int(s[m // 2])
+        d = b - a
+        want.append(a + (d // 2 if d >= 0 else -((-d) // 2)))
+    for rep in range(2):
+        res = device.new_results(len(cols), dev)
+        device.encode_batch_dev(descs, res)
+        rs = device.read_results(res)
+        assert [r.status for r in rs] == [0] * len(cols)
+        assert [r.midpoint for r in rs] == want, rep
+        assert all((r.width in (1, 2)) if i % 2 == 0 else r.width == 26 for i, r in enumerate(rs))

@@ -1,0 +1,110 @@
+"""GPU parity of the framed, batched encode (write_int_array_compressed for many arrays at once,
+binary.rs:639-645, 666-669): the frames must be the bytes the oracle's framing writes, back to
+back, whatever the mix of lengths, widths and element kinds."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from conftest import KINDS, column
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def env():
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need a device"
+    from oracle import zbra_oracle_c as oc
+    from zbra_amd import _lib, compression as zc, device
+    return torch, oc, zc, device, _lib
+
+
+def _mixed_arrays():
+    arrs = []
+    for i, kind in enumerate(KINDS):
+        for n in (0, 1, 9, 2049, 70001):
+            arrs.append(column(kind, n, 900 + 7 * i + n % 13))
+    rng = np.random.default_rng(1)
+    arrs.append(rng.integers(0, 5, 300001, dtype=np.int64).astype(np.uint32))   # enum tags
+    arrs.append(np.zeros(0, dtype=np.uint32))
+    arrs.append((rng.integers(0, 1 << 32, 5000, dtype=np.int64)).astype(np.uint32))
+    arrs.append(column("narrow", (1 << 21) + 3, 77))
+    return arrs
+
+
+def _want(oc, arrs):
+    frames = [oc.write_int_array_compressed(a.astype(np.int64)) for a in arrs]
+    offs = np.concatenate([[0], np.cumsum([len(f) for f in frames])])
+    return b"".join(frames), offs
+
+
+def test_host_frames_match_oracle(env):
+    _, oc, zc, _, _ = env
+    arrs = _mixed_arrays()
+    want, offs = _want(oc, arrs)
+    got, got_offs = zc.write_int_arrays_compressed(arrs)
+    assert np.array_equal(got_offs, offs)
+    assert got == want
+    empty, empty_offs = zc.write_int_arrays_compressed([])
+    assert empty == b"" and list(empty_offs) == [0]
+
+
+def test_many_small_arrays(env):
+    """More arrays than one scan step of the layout kernel handles (256), ragged and empty ones mixed in."""
+    _, oc, zc, _, _ = env
+    rng = np.random.default_rng(5)
+    arrs = []
+    for i in range(1500):
+        n = int(rng.integers(0, 40)) if i % 7 else int(rng.integers(2000, 6000))
+        arrs.append(column(KINDS[i % len(KINDS)], n, 3000 + i))
+    want, offs = _want(oc, arrs)
+    got, got_offs = zc.write_int_arrays_compressed(arrs)
+    assert np.array_equal(got_offs, offs) and got == want
+
+
+def test_host_frames_capacity(env):
+    _, oc, zc, _, L = env
+    arrs = [column("narrow", 5000, 1), column("w40", 3000, 2), column("small_signed", 100, 3), np.zeros(0, dtype=np.int64)]
+    want, offs = _want(oc, arrs)
+    vs = [np.ascontiguousarray(a) for a in arrs]
+    descs = (L.EncodeDesc * len(vs))()
+    for i, v in enumerate(vs):
+        descs[i].values = v.ctypes.data if v.size else None
+        descs[i].n = v.size
+        descs[i].kind = L.ELEM_I64
+    cap = int(offs[2]) - 1                                   # array 1 misses one byte
+    out = np.full(len(want) + 64, 0xAB, dtype=np.uint8)
+    offsets = (C.c_uint64 * (len(vs) + 1))()
+    statuses = (C.c_int * len(vs))()
+    st = L.lib.zbra_hip_encode_frames(descs, len(vs), out.ctypes.data_as(C.c_void_p), cap, offsets, statuses)
+    assert st == L.ERR_CAPACITY
+    assert list(statuses)[:3] == [0, L.ERR_CAPACITY, L.ERR_CAPACITY]
+    assert out[: offs[1]].tobytes() == want[: offs[1]]
+    assert (out[cap:] == 0xAB).all(), "wrote past cap"
+    # exact capacity is enough
+    st = L.lib.zbra_hip_encode_frames(descs, len(vs), out.ctypes.data_as(C.c_void_p), len(want), offsets, statuses)
+    assert st == 0 and list(offsets) == list(offs) and out[: len(want)].tobytes() == want
+    assert (out[len(want):] == 0xAB).all()
+
+
+def test_frames_dev_misaligned_with_guards(env):
+    torch, oc, _, device, L = env
+    arrs = [column(k, n, 40 + i) for i, (k, n) in enumerate([("narrow", 4097), ("full", 2048), ("binary", 1), ("constant", 0),
+                                                             ("w31", 10001), ("time_series", 5000)])]
+    want, offs = _want(oc, arrs)
+    d_vals = [torch.from_numpy(a).cuda() for a in arrs]
+    descs = device.make_encode_descs([(v.data_ptr() if v.numel() else None, v.numel(), None, 0, L.ELEM_I64) for v in d_vals])
+    for pad in (0, 1, 5):
+        buf = torch.full((pad + len(want) + 32,), 0xCD, dtype=torch.uint8, device="cuda")
+        d_off = torch.zeros(len(arrs) + 1, dtype=torch.int64, device="cuda")
+        res = device.new_results(len(arrs), "cuda")
+        device.encode_frames_dev(descs, buf[pad:pad + len(want)], d_off, res)
+        torch.cuda.synchronize()
+        assert np.array_equal(d_off.cpu().numpy(), offs)
+        got = buf.cpu().numpy()
+        assert got[pad:pad + len(want)].tobytes() == want, pad
+        assert (got[:pad] == 0xCD).all() and (got[pad + len(want):] == 0xCD).all(), "wrote outside the frames"
+        rs = device.read_results(res)
+        for i, a in enumerate(arrs):
+            assert rs[i].status == 0 and rs[i].out_count == offs[i + 1] - offs[i] - 8

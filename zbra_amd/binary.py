@@ -128,9 +128,29 @@ class Block:                                 # binary.rs:63-66
 # ---- writer (binary.rs:103-130, 184-356) ----------------------------------------------------
 
 class _Writer:
+    """The tree walk of write_to.  With a codec that has `write_int_arrays_compressed` (the GPU
+    one) the int arrays are only collected during the walk and encoded in ONE batched submission
+    at the end (`finish`), their frames then spliced in where the walk met them; with a
+    per-array codec (a test's stand-in) each array is encoded on the spot, as the reference does."""
+
     def __init__(self, codec):
         self.out = bytearray()
         self.codec = codec
+        self.batched = hasattr(codec, "write_int_arrays_compressed")
+        self.pending = []                                  # (position in self.out, array)
+
+    def finish(self) -> bytes:
+        if not self.pending:
+            return bytes(self.out)
+        frames, offs = self.codec.write_int_arrays_compressed([a for _, a in self.pending], as_bytes=False)
+        walk = memoryview(self.out)
+        parts, prev = [], 0
+        for i, (pos, _) in enumerate(self.pending):
+            parts.append(walk[prev:pos])
+            parts.append(memoryview(frames[offs[i]:offs[i + 1]]))
+            prev = pos
+        parts.append(walk[prev:])
+        return b"".join(parts)                             # the one copy of the image
 
     def u8(self, v):
         self.out.append(v)
@@ -158,6 +178,9 @@ class _Writer:
 
     def int_array(self, values):                           # write_int_array_compressed :639-645
         v = np.ascontiguousarray(values, dtype=np.int64)
+        if self.batched:
+            self.pending.append((len(self.out), v))
+            return
         self.u32(v.size)
         e = self.codec.compress_int_array(v)
         self.u32(len(e))
@@ -165,6 +188,9 @@ class _Writer:
 
     def u32_array(self, values):                           # write_u32_array_compressed :666-669
         v = np.ascontiguousarray(values, dtype=np.uint32)
+        if self.batched:
+            self.pending.append((len(self.out), v))
+            return
         self.u32(v.size)
         e = self.codec.compress_u32_array(v) if hasattr(self.codec, "compress_u32_array") \
             else self.codec.compress_int_array(v.astype(np.int64))
@@ -361,7 +387,7 @@ class BinaryFile:                            # binary.rs:56-59
         for b in self.blocks:                              # Block::write_to :184-192
             w.u32(b.row_count)
             w.table(b.table)
-        return bytes(w.out)
+        return w.finish()
 
     @classmethod
     def from_bytes(cls, image) -> "BinaryFile":            # read_from :139-174

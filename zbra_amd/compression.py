@@ -157,3 +157,28 @@ def decompress_u32_array(data, count: int):
     if st:
         _raise(st)
     return out[: n.value]
+
+
+def write_int_arrays_compressed(arrays, as_bytes=True):
+    """write_int_array_compressed / write_u32_array_compressed (binary.rs:639-645, 666-669) for a
+    list of arrays in one submission: returns (frames, offsets) where frames[offsets[i]:offsets[i+1]]
+    is `u32 count | u32 clen | E` of arrays[i].  uint32 arrays go the enum-tag way, everything else
+    is taken as int64.  as_bytes=False returns the frames as a uint8 array (no copy)."""
+    from ._lib import ELEM_I64, ELEM_U32, EncodeDesc
+    vs = [np.ascontiguousarray(a, dtype=np.uint32) if getattr(a, "dtype", None) == np.uint32 else _i64(a) for a in arrays]
+    n = len(vs)
+    descs = (EncodeDesc * max(1, n))()
+    bound = 0
+    for i, v in enumerate(vs):
+        descs[i].values = v.ctypes.data if v.size else None
+        descs[i].n = v.size
+        descs[i].kind = ELEM_U32 if v.dtype == np.uint32 else ELEM_I64
+        bound += 8 + lib.zbra_hip_encode_bound(v.size)
+    out = np.empty(bound, dtype=np.uint8)
+    offsets = (C.c_uint64 * (n + 1))()
+    statuses = (C.c_int * max(1, n))()
+    st = lib.zbra_hip_encode_frames(descs, n, _ptr(out) if bound else None, bound, offsets, statuses)
+    if st:
+        _raise(st)
+    offs = np.frombuffer(offsets, dtype=np.uint64).astype(np.int64)
+    return (out[: offs[n]].tobytes() if as_bytes else out[: offs[n]]), offs

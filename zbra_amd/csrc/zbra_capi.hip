@@ -211,13 +211,22 @@ struct EncodeItem {
 
 enum EncodeMode { ENCODE_FULL, ENCODE_MEDIAN_ONLY };
 
+// Framed output: every E is placed behind its `u32 count | u32 clen` header, back to back from
+// `out` (the items' own `out` / `cap` are ignored); offsets = nd + 1 device words.
+struct FrameTarget {
+    uint8_t *out = nullptr;
+    uint64_t cap = 0;
+    uint64_t *offsets = nullptr;
+};
+
 static int encode_batch_dev(DeviceCtx *ctx, const EncodeItem *items, size_t nd, zbra_dev_result *d_results,
-                            hipStream_t stream, EncodeMode mode = ENCODE_FULL) {
+                            hipStream_t stream, EncodeMode mode = ENCODE_FULL, const FrameTarget *frames = nullptr) {
     if (nd == 0) return ZBRA_OK;
     if (!items || nd > 0xFFFFFFFFull) return ZBRA_ERR_INVALID_ARG;
+    if (frames && (!frames->offsets || (frames->cap && !frames->out))) return ZBRA_ERR_INVALID_ARG;
     for (size_t i = 0; i < nd; i++) {
         if (items[i].n > MAX_COUNT || items[i].kind > KIND_U64_PLAIN) return ZBRA_ERR_INVALID_ARG;
-        if (items[i].n && (!items[i].values || (mode == ENCODE_FULL && !items[i].out))) return ZBRA_ERR_INVALID_ARG;
+        if (items[i].n && (!items[i].values || (mode == ENCODE_FULL && !frames && !items[i].out))) return ZBRA_ERR_INVALID_ARG;
     }
     const size_t off_ts = align_up(nd * sizeof(EncodeJob), 64);
     const size_t off_list = align_up(off_ts + (nd + 1) * sizeof(uint64_t), 64);  // arrays that may need select passes
@@ -289,6 +298,9 @@ static int encode_batch_dev(DeviceCtx *ctx, const EncodeItem *items, size_t nd, 
                 hipLaunchKernelGGL(enc_or_kernel, dim3(gs), dim3(THREADS), 0, stream, d_jobs, d_ts, (uint32_t)nd, ntiles);
         }
         if (mode == ENCODE_FULL) {
+            if (frames)
+                hipLaunchKernelGGL(enc_frame_layout_kernel, dim3(1), dim3(256), 0, stream, d_jobs, (uint32_t)nd, frames->out,
+                                   frames->cap, frames->offsets);
             hipLaunchKernelGGL(enc_finalize_kernel, dim3(ga), dim3(256), 0, stream, d_jobs, (uint32_t)nd, d_results);
             if (ntiles)
                 hipLaunchKernelGGL(enc_pack_kernel, dim3(grid_for(ntiles, pack_grid_cap())), dim3(THREADS), 0, stream, d_jobs, d_ts,
@@ -660,6 +672,84 @@ int zbra_hip_encode_batch_dev(const zbra_encode_desc *descs, size_t nd, zbra_dev
     std::vector<EncodeItem> items(nd);
     for (size_t i = 0; i < nd; i++) items[i] = EncodeItem{descs[i].values, descs[i].n, descs[i].kind, descs[i].out, descs[i].cap};
     return encode_batch_dev(ctx, items.data(), nd, d_results, (hipStream_t)stream);
+}
+
+int zbra_hip_encode_frames_dev(const zbra_encode_desc *descs, size_t nd, uint8_t *d_out, size_t cap, uint64_t *d_offsets,
+                               zbra_dev_result *d_results, void *stream) {
+    DeviceCtx *ctx;
+    ZBRA_TRY(current_ctx(&ctx));
+    if (!d_offsets || (nd && !descs)) return ZBRA_ERR_INVALID_ARG;
+    if (nd == 0) return hip_status(hipMemsetAsync(d_offsets, 0, sizeof(uint64_t), (hipStream_t)stream));
+    std::vector<EncodeItem> items(nd);
+    for (size_t i = 0; i < nd; i++) items[i] = EncodeItem{descs[i].values, descs[i].n, descs[i].kind, nullptr, 0};
+    FrameTarget ft;
+    ft.out = d_out; ft.cap = cap; ft.offsets = d_offsets;
+    return encode_batch_dev(ctx, items.data(), nd, d_results, (hipStream_t)stream, ENCODE_FULL, &ft);
+}
+
+int zbra_hip_encode_frames(const zbra_encode_desc *descs, size_t nd, uint8_t *out, size_t cap, uint64_t *offsets,
+                           int *statuses) {
+    if (!offsets || (nd && !descs) || (cap && !out)) return ZBRA_ERR_INVALID_ARG;
+    offsets[0] = 0;
+    if (nd == 0) return ZBRA_OK;
+    for (size_t i = 0; i < nd; i++) {
+        if (descs[i].n > MAX_COUNT || descs[i].kind > ZBRA_ELEM_U32 || (descs[i].n && !descs[i].values)) return ZBRA_ERR_INVALID_ARG;
+    }
+    DeviceCtx *ctx;
+    ZBRA_TRY(current_ctx(&ctx));
+    std::lock_guard<std::mutex> g(ctx->host_mu);
+    // Rounds of consecutive arrays: bounded input bytes and array count per submission.
+    constexpr size_t ROUND_IN = (size_t)2 << 30, ROUND_ARRAYS = 4096;
+    auto in_bytes = [&](size_t i) { return (size_t)((descs[i].n * (descs[i].kind == ZBRA_ELEM_I64 ? 8 : 4) + 15) / 16 * 16); };
+    std::vector<EncodeItem> items;
+    std::vector<HostPipe::Segment> segs;
+    size_t written = 0;
+    int first_err = ZBRA_OK;
+    for (size_t r0 = 0; r0 < nd;) {
+        size_t r1 = r0, total_in = 0, bound = 0;
+        while (r1 < nd && r1 - r0 < ROUND_ARRAYS && (r1 == r0 || total_in + in_bytes(r1) <= ROUND_IN)) {
+            total_in += in_bytes(r1);
+            bound += 8 + zbra_hip_encode_bound(descs[r1].n);
+            r1++;
+        }
+        const size_t nr = r1 - r0;
+        const size_t room = cap - written < bound ? cap - written : bound;  // what this round may fill
+        const size_t off_res = align_up((nr + 1) * sizeof(uint64_t), 64);
+        const size_t tmp_bytes = off_res + nr * sizeof(zbra_dev_result);
+        ZBRA_TRY(DeviceCtx::grow_dev(ctx->dev_in, total_in + 16));
+        ZBRA_TRY(DeviceCtx::grow_dev(ctx->dev_out, room + 16));
+        ZBRA_TRY(DeviceCtx::grow_dev(ctx->dev_tmp, tmp_bytes));
+        ZBRA_TRY(DeviceCtx::grow_pinned(ctx->pin_res, tmp_bytes));
+        items.resize(nr);
+        segs.clear();
+        size_t o = 0;
+        for (size_t i = 0; i < nr; i++) {  // the round's arrays go up as one stream, each at a 16-B aligned offset
+            const zbra_encode_desc &d = descs[r0 + i];
+            if (d.n) segs.push_back({o, const_cast<void *>(d.values), (size_t)d.n * (d.kind == ZBRA_ELEM_I64 ? 8 : 4)});
+            items[i] = EncodeItem{(char *)ctx->dev_in.ptr + o, d.n, d.kind, nullptr, 0};
+            o += in_bytes(r0 + i);
+        }
+        ZBRA_TRY(ctx->pipe.to_device_segments(segs.data(), segs.size(), ctx->dev_in.ptr, total_in, ctx->stream));
+        FrameTarget ft;
+        ft.out = (uint8_t *)ctx->dev_out.ptr; ft.cap = room; ft.offsets = (uint64_t *)ctx->dev_tmp.ptr;
+        ZBRA_TRY(encode_batch_dev(ctx, items.data(), nr, (zbra_dev_result *)((char *)ctx->dev_tmp.ptr + off_res), ctx->stream,
+                                  ENCODE_FULL, &ft));
+        ZBRA_HIP_TRY(hipMemcpyAsync(ctx->pin_res.ptr, ctx->dev_tmp.ptr, tmp_bytes, hipMemcpyDeviceToHost, ctx->stream));
+        ZBRA_HIP_TRY(hipStreamSynchronize(ctx->stream));
+        const uint64_t *h_off = (const uint64_t *)ctx->pin_res.ptr;
+        const zbra_dev_result *h_res = (const zbra_dev_result *)((const char *)ctx->pin_res.ptr + off_res);
+        const size_t laid_out = (size_t)h_off[nr];
+        ZBRA_TRY(ctx->pipe.to_host(out + written, ctx->dev_out.ptr, laid_out, ctx->stream));
+        for (size_t i = 0; i < nr; i++) {
+            offsets[r0 + i] = written + h_off[i];
+            if (statuses) statuses[r0 + i] = (int)h_res[i].status;
+            if (h_res[i].status != ZBRA_OK && first_err == ZBRA_OK) first_err = (int)h_res[i].status;
+        }
+        written += laid_out;
+        offsets[r1] = written;
+        r0 = r1;
+    }
+    return first_err;
 }
 
 int zbra_hip_file_index(const uint8_t *image, size_t len, zbra_file_array *arrays, size_t cap, zbra_file_info *info,

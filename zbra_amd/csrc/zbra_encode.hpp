@@ -366,13 +366,21 @@ __global__ __launch_bounds__(THREADS) void enc_bracket_kernel(EncodeJob *__restr
                 if (whole) bracket_values<SEL_BRACKET_HIST, true, 0, 2 * PAIRS>(x, v0, n, lo_b, hi_b, acc, lh, lcand, &lcount);
                 else bracket_values<SEL_BRACKET_HIST, false, 0, 2 * PAIRS>(x, v0, n, lo_b, hi_b, acc, lh, lcand, &lcount);
             } else {
-                // the LDS list takes half a tile's worth of appends between two looks at its fill
-                __syncthreads();  // every lane must see the same count, or the flush would split the workgroup
-                if (lcount + TILE / 2 > (uint32_t)CAND_LDS) flush_candidates();
+                // The LDS list takes half a tile's worth of appends between two looks at its fill.
+                // Every lane must take the same decision (the flush has barriers inside): the fill
+                // is read between two barriers, after the last append of the previous half and
+                // before the first of the next, so no lane can see a count another lane has
+                // already moved on from.
+                __syncthreads();
+                uint32_t staged = lcount;
+                __syncthreads();
+                if (staged + TILE / 2 > (uint32_t)CAND_LDS) flush_candidates();
                 if (whole) bracket_values<SEL_BRACKET_COMPACT, true, 0, PAIRS>(x, v0, n, lo_b, hi_b, acc, lh, lcand, &lcount);
                 else bracket_values<SEL_BRACKET_COMPACT, false, 0, PAIRS>(x, v0, n, lo_b, hi_b, acc, lh, lcand, &lcount);
                 __syncthreads();
-                if (lcount + TILE / 2 > (uint32_t)CAND_LDS) flush_candidates();
+                staged = lcount;
+                __syncthreads();
+                if (staged + TILE / 2 > (uint32_t)CAND_LDS) flush_candidates();
                 if (whole) bracket_values<SEL_BRACKET_COMPACT, true, PAIRS, 2 * PAIRS>(x, v0, n, lo_b, hi_b, acc, lh, lcand, &lcount);
                 else bracket_values<SEL_BRACKET_COMPACT, false, PAIRS, 2 * PAIRS>(x, v0, n, lo_b, hi_b, acc, lh, lcand, &lcount);
             }
@@ -657,6 +665,62 @@ __global__ __launch_bounds__(THREADS) void enc_or_kernel(EncodeJob *__restrict__
 }
 
 // ---- 5. header + pack ----------------------------------------------------------------------
+
+// Framed output (write_int_array_compressed, binary.rs:639-645): the arrays of a submission become
+// back-to-back frames `u32 count | u32 clen | E` in one buffer.  Sizes are known once the widths
+// are, so one workgroup scans them, points every job's `out` at its place behind its frame header,
+// writes the 8 header bytes and the offsets (offsets[nd] = total).  A frame that would pass `cap`
+// gets capacity 0, which the finalize kernel turns into ZBRA_ERR_CAPACITY; offsets then stop
+// growing, so offsets[nd] is the number of bytes actually laid out.
+__global__ __launch_bounds__(256) void enc_frame_layout_kernel(EncodeJob *__restrict__ jobs, uint32_t nd, uint8_t *out_base,
+                                                               uint64_t cap, uint64_t *__restrict__ offsets) {
+    __shared__ uint64_t scan[256];
+    __shared__ uint64_t carry;
+    const uint32_t tid = threadIdx.x;
+    if (tid == 0) carry = 0;
+    __syncthreads();
+    for (uint32_t a0 = 0; a0 < nd; a0 += 256) {
+        const uint32_t a = a0 + tid;
+        uint64_t e_len = 0, len = 0;
+        if (a < nd) {
+            EncodeJob &j = jobs[a];
+            if (j.n) {
+                const uint32_t w = j.need_or ? width_of(j.or_bits) : j.width;
+                e_len = 13 + (w >= 32 ? j.n * 8 : (j.n * w + 7) / 8);
+            }
+            len = 8 + e_len;
+        }
+        scan[tid] = len;
+        __syncthreads();
+        for (uint32_t d = 1; d < 256; d <<= 1) {  // inclusive scan of the 256 lengths
+            const uint64_t add = tid >= d ? scan[tid - d] : 0;
+            __syncthreads();
+            scan[tid] += add;
+            __syncthreads();
+        }
+        const uint64_t base = carry;
+        if (a < nd) {
+            EncodeJob &j = jobs[a];
+            const uint64_t end = base + scan[tid], off = end - len;
+            const bool fits = end <= cap;
+            offsets[a] = off < cap ? off : cap;
+            if (a == nd - 1) offsets[nd] = fits ? end : (off < cap ? off : cap);
+            if (fits) {
+                uint8_t *f = out_base + off;
+                const uint32_t cnt = (uint32_t)j.n, clen = (uint32_t)e_len;  // `as u32`, binary.rs:640-642
+                for (int b = 0; b < 4; b++) { f[b] = (uint8_t)(cnt >> (8 * b)); f[4 + b] = (uint8_t)(clen >> (8 * b)); }
+                j.out = f + 8;
+                j.cap = e_len;
+            } else {
+                j.out = nullptr;
+                j.cap = 0;
+            }
+        }
+        __syncthreads();
+        if (tid == 255) carry = base + scan[255];
+        __syncthreads();
+    }
+}
 
 // Writes midpoint | packed_len | width (compression.rs:131, 287-288) and the result words.
 __global__ void enc_finalize_kernel(EncodeJob *__restrict__ jobs, uint32_t nd, zbra_dev_result *results) {

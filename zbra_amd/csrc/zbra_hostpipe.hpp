@@ -191,40 +191,43 @@ struct HostPipe {
         return ZBRA_OK;
     }
 
-    void copy_pieces(size_t slot, char *dst, const char *src, size_t len) {
-        CopyWorkers &w = CopyWorkers::instance();
-        const int pieces = (int)((len + PIECE - 1) / PIECE);
-        pending[slot].store(pieces, std::memory_order_relaxed);
-        for (size_t o = 0; o < len; o += PIECE)
-            w.submit({dst + o, src + o, len - o < PIECE ? len - o : PIECE, &pending[slot]});
-    }
-
     void drain() {  // workers hold pointers into the caller's memory and the ring until they are done
         for (size_t i = 0; i < SLOTS; i++) CopyWorkers::instance().wait_zero(pending[i]);
     }
 
-    // host -> device.  Returns when `host` has been read completely; the device copy is ordered
-    // on `stream` like a hipMemcpyAsync.
-    int to_device(void *dev, const void *host, size_t bytes, hipStream_t stream) {
+    // A stretch of the device range and where it goes in host memory.
+    struct Segment {
+        size_t dev_off;
+        void *host;
+        size_t len;
+    };
+
+    // host -> device: the device range [dev, dev + bytes) is filled from the segments (sorted by
+    // dev_off, not overlapping; gaps are left as they are on the device side of the chunk, i.e.
+    // they receive whatever the ring held).  Returns when the host memory has been read
+    // completely; the device copies are ordered on `stream` like a hipMemcpyAsync.
+    int to_device_segments(const Segment *segs, size_t nsegs, void *dev, size_t bytes, hipStream_t stream) {
         if (bytes < MIN_BYTES || !enabled()) {
-            if (bytes) ZBRA_HIP_TRY(hipMemcpyAsync(dev, host, bytes, hipMemcpyHostToDevice, stream));
+            for (size_t j = 0; j < nsegs; j++)
+                if (segs[j].len)
+                    ZBRA_HIP_TRY(hipMemcpyAsync((char *)dev + segs[j].dev_off, segs[j].host, segs[j].len, hipMemcpyHostToDevice, stream));
             return ZBRA_OK;
         }
         ZBRA_TRY(ensure(chunk_for(bytes)));
-        const int st = stage_to_device(dev, host, bytes, stream);
+        const int st = stage_to_device(segs, nsegs, dev, bytes, stream);
         drain();
         return st;
     }
 
-    int stage_to_device(void *dev, const void *host, size_t bytes, hipStream_t stream) {
+    int stage_to_device(const Segment *segs, size_t nsegs, void *dev, size_t bytes, hipStream_t stream) {
         CopyWorkers &w = CopyWorkers::instance();
         const size_t chunk = chunk_for(bytes), nchunks = (bytes + chunk - 1) / chunk;
-        size_t staged = 0, sent = 0;
+        size_t staged = 0, sent = 0, si = 0;
         while (sent < nchunks) {
             while (staged < nchunks && staged - sent < SLOTS) {
                 const size_t slot = staged % SLOTS, off = staged * chunk;
                 ZBRA_TRY(slot_idle(slot));  // the DMA that last read this slot has finished
-                copy_pieces(slot, ring + slot * slot_bytes, (const char *)host + off, bytes - off < chunk ? bytes - off : chunk);
+                deliver<false>(slot, ring + slot * slot_bytes, off, bytes - off < chunk ? bytes - off : chunk, segs, nsegs, si);
                 staged++;
             }
             const size_t slot = sent % SLOTS, off = sent * chunk;
@@ -238,17 +241,17 @@ struct HostPipe {
         return ZBRA_OK;
     }
 
-    // A stretch of the device range and where it goes in host memory.
-    struct Segment {
-        size_t dev_off;
-        void *host;
-        size_t len;
-    };
+    int to_device(void *dev, const void *host, size_t bytes, hipStream_t stream) {
+        const Segment whole{0, const_cast<void *>(host), bytes};
+        return to_device_segments(&whole, 1, dev, bytes, stream);
+    }
 
-    // Queues the memcpys that take the part [off, off + len) of the device range, now at `src`,
-    // to the segments it overlaps.  `si` is the first segment that can still overlap (segments
-    // are sorted by dev_off and do not overlap; gaps are padding that goes nowhere).
-    void deliver(size_t slot, const char *src, size_t off, size_t len, const Segment *segs, size_t nsegs, size_t &si) {
+    // Queues the memcpys between the ring image `img` of the part [off, off + len) of the device
+    // range and the segments that part overlaps: TO_HOST true = image -> segments, false =
+    // segments -> image.  `si` is the first segment that can still overlap (segments are sorted by
+    // dev_off and do not overlap; gaps are padding).
+    template <bool TO_HOST>
+    void deliver(size_t slot, char *img, size_t off, size_t len, const Segment *segs, size_t nsegs, size_t &si) {
         CopyWorkers &w = CopyWorkers::instance();
         while (si < nsegs && segs[si].dev_off + segs[si].len <= off) si++;
         int pieces = 0;
@@ -262,7 +265,8 @@ struct HostPipe {
                 const size_t end = segs[j].dev_off + segs[j].len, hi = end < off + len ? end : off + len;
                 for (size_t o = lo; o < hi; o += PIECE) {
                     if (pass == 0) { pieces++; continue; }
-                    w.submit({(char *)segs[j].host + (o - segs[j].dev_off), src + (o - off), hi - o < PIECE ? hi - o : PIECE, &pending[slot]});
+                    char *h = (char *)segs[j].host + (o - segs[j].dev_off), *r = img + (o - off);
+                    w.submit({TO_HOST ? h : r, TO_HOST ? r : h, hi - o < PIECE ? hi - o : PIECE, &pending[slot]});
                 }
             }
         }
@@ -304,7 +308,7 @@ struct HostPipe {
             if (st != ZBRA_OK) break;
             const size_t slot = landed % SLOTS, off = landed * chunk;
             if ((st = slot_idle(slot)) != ZBRA_OK) break;
-            deliver(slot, ring + slot * slot_bytes, off, bytes - off < chunk ? bytes - off : chunk, segs, nsegs, si);
+            deliver<true>(slot, ring + slot * slot_bytes, off, bytes - off < chunk ? bytes - off : chunk, segs, nsegs, si);
             landed++;
         }
         drain();

@@ -102,6 +102,16 @@ def make_encode_descs(items):
     return arr
 
 
+def encode_frames_dev(descs, out: torch.Tensor, offsets: torch.Tensor, results=None, stream=None):
+    """zbra_hip_encode_frames_dev: frames `u32 count | u32 clen | E` back to back in `out` (uint8);
+    `offsets` is an int64/uint64 device tensor of len(descs) + 1 words."""
+    assert offsets.numel() >= len(descs) + 1 and offsets.element_size() == 8
+    st = lib.zbra_hip_encode_frames_dev(descs, len(descs), out.data_ptr(), out.numel(), offsets.data_ptr(),
+                                        results.data_ptr() if results is not None else None, _stream_handle(stream))
+    if st:
+        _raise(st)
+
+
 def encode_batch_dev(descs, results: torch.Tensor, stream=None):
     st = lib.zbra_hip_encode_batch_dev(descs, len(descs), results.data_ptr(), _stream_handle(stream))
     if st:
