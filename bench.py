@@ -130,6 +130,11 @@ def main():
     device.encode_dev(values, enc_buf, res)
     r = device.read_results(res)[0]
     assert r.status == 0 and r.width == 12, (r.status, r.width)
+    # decode(encode(v)) == v holds for ANY midpoint, so the median is checked on its own (untimed)
+    srt = torch.sort(values).values
+    lo_med, hi_med = int(srt[n // 2 - 1]), int(srt[n // 2])
+    del srt
+    assert r.midpoint == lo_med + (hi_med - lo_med) // 2, (r.midpoint, lo_med, hi_med)  # both positive: trunc = floor
     enc_len = int(r.out_count)
     assert enc_len == 13 + (n * 12 + 7) // 8
     encoded = enc_buf[:enc_len].clone()  # exact-size copy: E at its own allocation
