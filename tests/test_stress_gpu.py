@@ -1,0 +1,20 @@
+"""Randomised batches at sizes beyond the CPU oracle's reach: every array's midpoint against a
+device sort, its width against the zig-zag maximum, then the batch's round trip (the generator
+and the checks live in scripts/stress_encode.py, which runs longer campaigns)."""
+import os
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scripts"))
+
+
+@pytest.mark.parametrize("seed,max_log2,max_arrays", [(1, 23, 300), (2, 23, 300), (1003, 23, 300), (5004, 26, 12), (20005, 14, 3000)])
+def test_random_batches(seed, max_log2, max_arrays):
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need a device"
+    import stress_encode
+    from zbra_amd import _lib, device
+    assert stress_encode.run_trial(torch, device, _lib, seed, max_log2, max_arrays) > 0
