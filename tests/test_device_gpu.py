@@ -232,3 +232,42 @@ def test_decode_garbage_never_reads_or_writes_outside(env):
             assert (got[8 + expect.size:8 + count] == -77).all()
         else:
             assert (got == -77).all()
+
+
+def test_dev_calls_from_threads_on_own_streams(env):
+    """Stream-ordered calls may be issued from several threads on different streams: each borrows
+    its own workspace slot (descriptor tables, candidate lists), so concurrent submissions must
+    not see each other's state."""
+    import threading
+    torch, device, oc, L = env
+    kinds = ["narrow", "w31", "full", "small_signed", "w40", "binary"]
+    n = 300_001
+    cols = [column(k, n, 70 + i) for i, k in enumerate(kinds)]
+    want = [oc.compress_int_array(c) for c in cols]
+    errs = []
+
+    def work(i):
+        try:
+            st = torch.cuda.Stream()
+            v = torch.from_numpy(cols[i]).cuda()
+            enc = torch.empty(device.encode_bound(n), dtype=torch.uint8, device="cuda")
+            out = torch.empty(n, dtype=torch.int64, device="cuda")
+            res, dres = device.new_results(1, "cuda"), device.new_results(1, "cuda")
+            torch.cuda.synchronize()
+            for _ in range(20):
+                device.encode_dev(v, enc, res, stream=st)
+                device.decode_dev(enc, n, out, dres, length=len(want[i]), stream=st)
+            st.synchronize()
+            r = device.read_results(res)[0]
+            assert r.status == 0 and r.out_count == len(want[i])
+            assert enc[:len(want[i])].cpu().numpy().tobytes() == want[i]
+            assert torch.equal(out, v)
+        except Exception as ex:  # noqa: BLE001
+            errs.append((i, repr(ex)))
+
+    ts = [threading.Thread(target=work, args=(i,)) for i in range(len(kinds))]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert not errs, errs
