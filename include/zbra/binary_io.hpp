@@ -4,6 +4,7 @@
 // (no intermediate Vec<i64> as in binary.rs:666-674); the usize variant is the i64 path.
 #pragma once
 #include <cstring>
+#include <string>
 
 #include "compression.hpp"
 
@@ -91,6 +92,74 @@ inline Result<std::vector<uint32_t>> read_u32_array_compressed(Reader &r) {
     if (st != ZBRA_OK) return detail::make_error(st, BinaryError::DecompressionError);
     out.resize(got);
     return out;
+}
+
+// ---- batched forms: what a writer / reader of a whole file uses ----------------------------------
+
+// One int array of a tree walk: Int values, Double bits, lengths (all 8-byte elements) or enum
+// tags (4-byte elements).
+struct IntArrayRef {
+    const void *values;
+    size_t n;
+    bool is_u32;
+    IntArrayRef(const std::vector<int64_t> &v) : values(v.data()), n(v.size()), is_u32(false) {}
+    IntArrayRef(const std::vector<uint32_t> &v) : values(v.data()), n(v.size()), is_u32(true) {}
+};
+
+// write_int_array_compressed / write_u32_array_compressed (binary.rs:639-645, 666-669) for every
+// array of `arrays` in ONE submission: their frames are appended to `w` back to back;
+// frame i = w[offsets[i] .. offsets[i+1]) relative to w's size at the call.
+inline Result<std::vector<size_t>> write_int_arrays_compressed(std::vector<uint8_t> &w, const std::vector<IntArrayRef> &arrays) {
+    std::vector<zbra_encode_desc> descs(arrays.size());
+    size_t bound = 0;
+    for (size_t i = 0; i < arrays.size(); i++) {
+        descs[i] = zbra_encode_desc{arrays[i].values, arrays[i].n, nullptr, 0,
+                                    (uint32_t)(arrays[i].is_u32 ? ZBRA_ELEM_U32 : ZBRA_ELEM_I64), 0};
+        bound += 8 + zbra_hip_encode_bound(arrays[i].n);
+    }
+    const size_t at = w.size();
+    w.resize(at + bound);
+    std::vector<uint64_t> offs(arrays.size() + 1);
+    const int st = zbra_hip_encode_frames(descs.data(), descs.size(), w.data() + at, bound, offs.data(), nullptr);
+    if (st != ZBRA_OK) { w.resize(at); return detail::make_error(st, BinaryError::CompressionError); }
+    w.resize(at + offs.back());
+    return std::vector<size_t>(offs.begin(), offs.end());
+}
+
+// Every int array of a .zbra image, found without decoding (zbra_hip_file_index) and then decoded
+// in one pipelined pass (zbra_hip_file_decode): BinaryFile::read_from's int arrays
+// (binary.rs:139-174, 359-441) in file order.  Enum tags land in `u32`, everything else in `i64`.
+struct DecodedArray {
+    zbra_file_array where;
+    std::vector<int64_t> i64;
+    std::vector<uint32_t> u32;
+};
+struct DecodedFile {
+    zbra_file_info info;
+    std::vector<DecodedArray> arrays;
+};
+inline Result<DecodedFile> read_file_int_arrays(const uint8_t *image, size_t len) {
+    DecodedFile f;
+    size_t err_at = 0;
+    int st = zbra_hip_file_index(image, len, nullptr, 0, &f.info, &err_at);
+    if (st != ZBRA_OK) return BinaryError{BinaryError::DecompressionError, std::string(zbra_hip_strerror(st)) + " at offset " + std::to_string(err_at), st};
+    std::vector<zbra_file_array> idx(f.info.n_arrays);
+    if (!idx.empty()) {
+        st = zbra_hip_file_index(image, len, idx.data(), idx.size(), &f.info, &err_at);
+        if (st != ZBRA_OK) return detail::make_error(st, BinaryError::DecompressionError);
+    }
+    f.arrays.resize(idx.size());
+    std::vector<void *> outs(idx.size());
+    for (size_t i = 0; i < idx.size(); i++) {
+        f.arrays[i].where = idx[i];
+        if (idx[i].kind == ZBRA_ELEM_U32) { f.arrays[i].u32.resize(idx[i].count); outs[i] = f.arrays[i].u32.data(); }
+        else { f.arrays[i].i64.resize(idx[i].count); outs[i] = f.arrays[i].i64.data(); }
+    }
+    st = zbra_hip_file_decode(image, len, idx.data(), idx.size(), outs.data(), nullptr);
+    if (st != ZBRA_OK) return detail::make_error(st, BinaryError::DecompressionError);
+    for (size_t i = 0; i < idx.size(); i++)
+        if (idx[i].len == 0) { f.arrays[i].i64.clear(); f.arrays[i].u32.clear(); }  // empty data -> empty Vec, compression.rs:296-298
+    return f;
 }
 
 }  // namespace binary

@@ -174,6 +174,78 @@ static void test_framing() {
     CHECK(zbra::binary::read_int_array_compressed(r).is_err());  // EOF
 }
 
+// A whole image through the batched writer and the indexed reader: Blocks of an Enum column (tags
+// + one Int column per variant), written with the container grammar of binary.rs:103-130, 184-356.
+static void test_file_write_and_read_batched() {
+    using namespace zbra::binary;
+    const int nblocks = 3;
+    std::vector<std::vector<uint32_t>> tags(nblocks);
+    std::vector<std::vector<int64_t>> va(nblocks), vb(nblocks);
+    for (int b = 0; b < nblocks; b++) {
+        const int rows = 1000 + 777 * b;
+        for (int i = 0; i < rows; i++) {
+            const uint32_t t = (uint32_t)((i * 7 + b) % 3 == 0);
+            tags[b].push_back(t);
+            if (t == 0) va[b].push_back(1700000000000LL + (i * 7919) % 4000);
+            else vb[b].push_back((int64_t)i * 1000003 - 5000000000LL);
+        }
+    }
+    // first walk: everything but the int arrays, remembering where each frame goes
+    std::vector<uint8_t> walk;
+    std::vector<size_t> at;
+    std::vector<IntArrayRef> refs;
+    auto bytes = [&](const char *s) { walk.insert(walk.end(), s, s + std::strlen(s)); };
+    auto sized = [&](const char *s) { write_u32(walk, (uint32_t)std::strlen(s)); write_u32(walk, (uint32_t)std::strlen(s)); bytes(s); };
+    auto str = [&](const char *s) { write_u32(walk, (uint32_t)std::strlen(s)); bytes(s); };
+    auto int_column = [&](const std::vector<int64_t> &v) {
+        walk.push_back(1); walk.push_back(0); walk.push_back(0); walk.push_back(0);  // Int, Allow, int encoding, Int
+        at.push_back(walk.size()); refs.emplace_back(v);
+    };
+    bytes("||_ZBRA||00001||");
+    sized("{}");
+    sized("{\"binary_data\":\"None\",\"strings\":\"None\"}");
+    write_u32(walk, nblocks);
+    for (int b = 0; b < nblocks; b++) {
+        write_u32(walk, (uint32_t)tags[b].size());
+        walk.push_back(1); walk.push_back(0);   // Table::Array, Allow
+        walk.push_back(6); walk.push_back(0);   // Column::Enum, Allow
+        at.push_back(walk.size()); refs.emplace_back(tags[b]);
+        write_u32(walk, 2);
+        str("a"); write_u32(walk, 0); int_column(va[b]);
+        str("b"); write_u32(walk, 1); int_column(vb[b]);
+    }
+    // one batched encode, frames spliced in
+    std::vector<uint8_t> frames;
+    auto offs = write_int_arrays_compressed(frames, refs).unwrap();
+    std::vector<uint8_t> image;
+    size_t prev = 0;
+    for (size_t i = 0; i < refs.size(); i++) {
+        image.insert(image.end(), walk.begin() + prev, walk.begin() + at[i]);
+        image.insert(image.end(), frames.begin() + offs[i], frames.begin() + offs[i + 1]);
+        prev = at[i];
+    }
+    image.insert(image.end(), walk.begin() + prev, walk.end());
+    // each frame is what the per-array helper (and the oracle) writes
+    for (int b = 0; b < nblocks; b++) {
+        std::vector<uint8_t> ow(8 + zo_compress_bound(va[b].size()));
+        ow.resize(zo_write_int_array_compressed(va[b].data(), va[b].size(), ow.data()));
+        const size_t i = 3 * b + 1;
+        CHECK(std::vector<uint8_t>(frames.begin() + offs[i], frames.begin() + offs[i + 1]) == ow);
+        std::vector<uint8_t> tw;
+        CHECK(write_u32_array_compressed(tw, tags[b]).is_ok());
+        CHECK(std::vector<uint8_t>(frames.begin() + offs[3 * b], frames.begin() + offs[3 * b + 1]) == tw);
+    }
+    auto f = read_file_int_arrays(image.data(), image.size()).unwrap();
+    CHECK(f.info.block_count == (uint32_t)nblocks && f.info.n_arrays == (uint64_t)3 * nblocks && f.info.end_offset == image.size());
+    for (int b = 0; b < nblocks; b++) {
+        CHECK(f.arrays[3 * b].where.role == ZBRA_ROLE_ENUM_TAGS && f.arrays[3 * b].u32 == tags[b]);
+        CHECK(f.arrays[3 * b + 1].where.role == ZBRA_ROLE_INT_VALUES && f.arrays[3 * b + 1].i64 == va[b]);
+        CHECK(f.arrays[3 * b + 2].i64 == vb[b] && f.arrays[3 * b + 2].where.block == (uint32_t)b);
+    }
+    image[3] ^= 0x40;  // magic number
+    CHECK(read_file_int_arrays(image.data(), image.size()).is_err());
+}
+
 int main() {
     int ndev = 0;
     if (zbra_hip_device_count(&ndev) != ZBRA_OK || ndev == 0) { std::printf("no device: these tests need a GPU\n"); return 2; }
@@ -187,6 +259,7 @@ int main() {
     test_frame_of_reference_effectiveness();
     test_error_conventions();
     test_framing();
+    test_file_write_and_read_batched();
     std::printf("%d checks, %d failures\n", checks, failures);
     return failures ? 1 : 0;
 }
