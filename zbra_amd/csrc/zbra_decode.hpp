@@ -326,15 +326,6 @@ __device__ __forceinline__ void tile_fill(const DecodePlan &p, uint64_t v0, uint
     }
 }
 
-// Tile handled by workgroup b when there is one workgroup per tile.  Workgroups are dealt to
-// the 8 XCDs round-robin (b % 8 labels the XCD), so this gives each XCD one contiguous eighth
-// of the tile range: every L2 then streams one region of memory instead of every eighth tile
-// (+9 % store bandwidth measured).  Bijective for any ntiles.  Affects speed only.
-__device__ __forceinline__ uint64_t xcd_chunked_tile(uint64_t b, uint64_t ntiles) {
-    const uint64_t q = ntiles >> 3, r = ntiles & 7, xcd = b & 7;
-    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
-}
-
 // One tile of one array.
 template <int DT, int TH, int NT, bool DIRECT>
 __device__ __forceinline__ void decode_tile(const DecodePlan &p, uint64_t tile_in_array, uint32_t *lds) {

@@ -800,7 +800,7 @@ __device__ __forceinline__ void pack_tile_packed(const EncodeJob &job, uint64_t 
         v.w = stream_dword(zz, lo + 96, w, inv);
         const uintptr_t addr = G0 + (uintptr_t)c * 16;
         if (addr >= G && addr + 16 <= Gend) {
-            *gptr_mut<u32x4>(addr) = v;
+            __builtin_nontemporal_store(v, gptr_mut<u32x4>(addr));  // streamed out once: -2 % on the whole encode
         } else {  // head / tail chunk shared with a neighbour: only this tile's bytes
             const uint32_t d[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
@@ -843,7 +843,7 @@ __device__ __forceinline__ void pack_tile_raw(const EncodeJob &job, uint64_t v0,
         const uintptr_t addr = G0 + (uintptr_t)c * 16;
         if (addr >= G && addr + 16 <= Gend) {
             u64x2 v = {o0, o1};
-            *gptr_mut<u64x2>(addr) = v;
+            __builtin_nontemporal_store(v, gptr_mut<u64x2>(addr));
         } else {
 #pragma unroll
             for (int b = 0; b < 16; b++) {
@@ -867,9 +867,11 @@ __global__ void enc_report_median_kernel(const EncodeJob *__restrict__ jobs, uin
 
 __global__ __launch_bounds__(THREADS) void enc_pack_kernel(const EncodeJob *__restrict__ jobs,
                                                             const uint64_t *__restrict__ tile_start, uint32_t nd,
-                                                            uint64_t ntiles) {
+                                                            uint64_t ntiles, uint32_t xcd_chunked) {
     __shared__ __attribute__((aligned(16))) uint32_t zz[TILE];
-    for (uint64_t t = blockIdx.x; t < ntiles; t += gridDim.x) {
+    // xcd_chunked implies gridDim.x == ntiles: exactly one trip through the loop
+    uint64_t t = xcd_chunked ? xcd_chunked_tile(blockIdx.x, ntiles) : blockIdx.x;
+    for (; t < ntiles; t += gridDim.x) {
         const uint32_t a = nd > 1 ? find_array(tile_start, nd, t) : 0;
         const EncodeJob &job = jobs[a];
         if (job.width == WIDTH_SKIP) continue;
