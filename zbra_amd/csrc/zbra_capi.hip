@@ -287,14 +287,17 @@ static int encode_batch_dev(DeviceCtx *ctx, const EncodeItem *items, size_t nd, 
         if (ntiles) {
             hipLaunchKernelGGL(enc_sample_kernel, dim3((unsigned)nd), dim3(SAMPLE_THREADS), 0, stream, d_jobs, (uint32_t)nd,
                                bracket ? 1u : 0u);
-            hipLaunchKernelGGL(enc_bracket_kernel, dim3(gs), dim3(THREADS), 0, stream, d_jobs, d_ts, (uint32_t)nd, ntiles, d_hist);
+            // arrays outside the list (sorted whole by the sample kernel, or plain u64) need
+            // neither the bracket pass nor any select pass: a submission of short arrays is five
+            // launches, not eighteen
+            if (n_list)
+                hipLaunchKernelGGL(enc_bracket_kernel, dim3(gs), dim3(THREADS), 0, stream, d_jobs, d_ts, (uint32_t)nd, ntiles, d_hist);
         }
         hipLaunchKernelGGL(enc_setup_kernel, dim3((unsigned)nd), dim3(THREADS), 0, stream, d_jobs, (uint32_t)nd, d_hist);
         if (ntiles) {
-            for (uint32_t pass = 0; pass < (uint32_t)MAX_PASSES; pass++) {
-                if (n_list)
-                    hipLaunchKernelGGL(enc_hist_kernel, dim3(n_list * per_array), dim3(THREADS), 0, stream, d_jobs, d_list, n_list,
-                                       per_array, d_hist, pass);
+            for (uint32_t pass = 0; n_list && pass < (uint32_t)MAX_PASSES; pass++) {
+                hipLaunchKernelGGL(enc_hist_kernel, dim3(n_list * per_array), dim3(THREADS), 0, stream, d_jobs, d_list, n_list,
+                                   per_array, d_hist, pass);
                 hipLaunchKernelGGL(enc_select_kernel, dim3((unsigned)nd), dim3(THREADS), 0, stream, d_jobs, d_hist, pass);
             }
             if (mode == ENCODE_FULL)
