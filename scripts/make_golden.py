@@ -15,6 +15,9 @@ Inputs come from the reference's own tests:
   proptest-regressions/compression.txt:7-11 overflow seeds
   tests/compression-pipeline.rs:9-16,96,101,172-176 deterministic inputs
   zbra-cli/src/main.rs:384                  numbers.json example
+A third layer, "stages", holds the one worked example the reference PUBLISHES with its
+intermediate results (docs/compression-pipeline.md:27-82: median, deltas, zig-zag values, bit
+width): numbers stated by the reference's own documentation, not derived here.
 """
 import json
 import os
@@ -63,10 +66,18 @@ PACK = [
 ]
 
 
+# worked example of docs/compression-pipeline.md:27-33 (median, deltas), :52-56 (zig-zag), :77-82 (width)
+STAGES = [
+    ("Q", [4102444800000, 4102448400000, 4102451600000],
+     {"median": 4102448400000, "deltas": [-3600000, 0, 3200000], "zigzag": [7199999, 0, 6400000], "w": 23},
+     "docs/compression-pipeline.md:27-33, 52-56, 77-82"),
+]
+
+
 def main():
     out = {"note": "hand = derived by hand from compression.rs; hex = bytes on which the C and numpy "
                    "restatements agree. Not produced by running the reference.",
-           "pipeline": [], "pack": []}
+           "pipeline": [], "pack": [], "stages": []}
     for name, values, mid, w, length, hexs, origin in PIPELINE:
         ec = oc.compress_int_array(values)
         en = on.compress_int_array(values)
@@ -94,10 +105,21 @@ def main():
         assert rc == 0 and back.tolist() == values
         out["pack"].append({"name": name, "origin": origin, "values": [str(v) for v in values],
                             "hand": {"w": w, "packed_len": plen}, "hex": pc.hex()})
+    for name, values, pub, origin in STAGES:
+        for o in (oc, on):
+            mid, deltas = o.frame_of_reference_encode(values)
+            assert int(mid) == pub["median"] and [int(d) for d in deltas] == pub["deltas"], name
+            zz = o.zig_zag_encode(deltas)
+            assert [int(z) for z in zz] == pub["zigzag"], name
+            assert o.bp64_pack(zz)[0] == pub["w"], name
+        out["stages"].append({"name": name, "origin": origin, "values": [str(v) for v in values],
+                              "published": {"median": str(pub["median"]), "deltas": [str(d) for d in pub["deltas"]],
+                                            "zigzag": [str(z) for z in pub["zigzag"]], "w": pub["w"]},
+                              "hex": oc.compress_int_array(values).hex()})
     path = os.path.join(ROOT, "tests", "golden", "known_answers.json")
     with open(path, "w") as f:
         json.dump(out, f, indent=1)
-    print("wrote", path, len(out["pipeline"]), "pipeline +", len(out["pack"]), "pack vectors")
+    print("wrote", path, len(out["pipeline"]), "pipeline +", len(out["pack"]), "pack +", len(out["stages"]), "stage vectors")
 
 
 if __name__ == "__main__":

@@ -36,6 +36,21 @@ def test_golden_pack(golden, name, o):
         assert st == 0 and back.tolist() == values
 
 
+@pytest.mark.parametrize("name,o", ORACLES)
+def test_golden_stages_published_by_the_reference(golden, name, o):
+    """docs/compression-pipeline.md:27-82: the one example whose intermediate results the reference states."""
+    assert golden["stages"]
+    for vec in golden["stages"]:
+        values = [int(v) for v in vec["values"]]
+        pub = vec["published"]
+        mid, deltas = o.frame_of_reference_encode(values)
+        assert int(mid) == int(pub["median"]) and [int(d) for d in deltas] == [int(d) for d in pub["deltas"]]
+        zz = o.zig_zag_encode(deltas)
+        assert [int(z) for z in zz] == [int(z) for z in pub["zigzag"]]
+        assert o.bp64_pack(zz)[0] == pub["w"]
+        assert o.compress_int_array(values).hex() == vec["hex"]
+
+
 @pytest.mark.parametrize("kind", KINDS)
 def test_c_and_numpy_agree(kind):
     for n in [s for s in SIZES if s <= 10000]:

@@ -39,6 +39,22 @@ def test_golden_pack(zc, golden):
         assert np.array_equal(zc.bp64_unpack(bytes.fromhex(vec["hex"]), values.size), values), vec["name"]
 
 
+def test_golden_stages_published_by_the_reference(zc, golden):
+    """docs/compression-pipeline.md:27-82: median, deltas, zig-zag values and bit width as the
+    reference's documentation states them, through the stage functions on the device."""
+    for vec in golden["stages"]:
+        values = np.array([int(v) for v in vec["values"]], dtype=np.int64)
+        pub = vec["published"]
+        mid, deltas = zc.frame_of_reference_encode(values)
+        assert int(mid) == int(pub["median"]) and [int(d) for d in deltas] == [int(d) for d in pub["deltas"]]
+        zz = zc.zig_zag_encode(deltas)
+        assert [int(z) for z in zz] == [int(z) for z in pub["zigzag"]]
+        packed = zc.bp64_pack(zz)
+        assert packed[0] == pub["w"]
+        assert np.array_equal(zc.zig_zag_decode(zc.bp64_unpack(packed, values.size)), deltas)
+        assert zc.compress_int_array(values).hex() == vec["hex"]
+
+
 @pytest.mark.parametrize("kind", KINDS)
 def test_pipeline_matches_oracle(zc, oc, kind):
     for n in SIZES:
