@@ -202,3 +202,17 @@ def test_file_decode_groups_and_statuses():
     for i, (k, n) in enumerate(cols):
         if i != 3:
             assert np.array_equal(outs[i], column(k, n, 50 + i)), i
+
+
+def test_walker_fuzz_under_sanitizers(tmp_path):
+    """The walker is host code that reads untrusted bytes: random trees, every truncation and random
+    corruptions under AddressSanitizer + UBSan (tests/cpp/fuzz_walker.cpp)."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "fuzz_walker")
+    subprocess.run(["g++", "-O1", "-g", "-std=c++17", "-fsanitize=address,undefined", "-fno-sanitize-recover=all", "-static-libasan",
+                    "-I" + os.path.join(root, "include"), os.path.join(root, "tests", "cpp", "fuzz_walker.cpp"), "-o", exe], check=True)
+    r = subprocess.run([exe, "4000", "7"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "4000 valid images indexed exactly" in r.stdout
