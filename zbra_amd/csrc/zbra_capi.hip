@@ -430,7 +430,9 @@ static int decode_host(const uint8_t *data, size_t len, size_t count, void *out,
     ZBRA_TRY(current_ctx(&ctx));
     std::lock_guard<std::mutex> g(ctx->host_mu);
     const size_t esz = kind == ZBRA_ELEM_I64 ? 8 : 4;
-    const size_t used = 12 + (size_t)(*(const uint32_t *)(data + 8));  // bytes after 12 + packed_len are ignored
+    uint32_t packed_len;
+    std::memcpy(&packed_len, data + 8, 4);               // E sits at any byte address
+    const size_t used = 12 + (size_t)packed_len;         // bytes after 12 + packed_len are ignored
     ZBRA_TRY(DeviceCtx::grow_dev(ctx->dev_in, used + 16));
     ZBRA_TRY(DeviceCtx::grow_dev(ctx->dev_out, count * esz));
     if (count * esz >= 2 * HOST_PIECE_BYTES && HostPipe::enabled()) return decode_host_pieces(ctx, data, used, count, out, kind);
