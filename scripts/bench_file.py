@@ -1,0 +1,101 @@
+#!/usr/bin/env python3
+"""The full-file configuration on one GPU, scaled down: a .zbra image of `--blocks` Blocks of
+2^`--rows-log2` rows x 4 Int columns (entity id: clustered runs, attribute id: <= 8 bits, time:
+milliseconds, monotone, value: <= 12 bits), written by this package's batched writer.  Measures
+(i) the batched decode alone, image and values resident in HBM, and (ii) image in pageable host
+memory -> values in host memory through zbra_hip_file_index + zbra_hip_file_decode.  The scale
+(64 GB per file in the full configuration) is stated in the output."""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np
+
+
+def sm(seed, i):
+    z = (np.uint64(seed) + (i + np.uint64(1)) * np.uint64(0x9E3779B97F4A7C15))
+    z ^= z >> np.uint64(30); z *= np.uint64(0xBF58476D1CE4E5B9)
+    z ^= z >> np.uint64(27); z *= np.uint64(0x94D049BB133111EB)
+    z ^= z >> np.uint64(31)
+    return z
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--blocks", type=int, default=24)
+    ap.add_argument("--rows-log2", type=int, default=22)
+    ap.add_argument("--reps", type=int, default=3)
+    args = ap.parse_args()
+    import torch
+
+    from zbra_amd import _lib, binary as zb, device
+    n = 1 << args.rows_log2
+    blocks = []
+    with np.errstate(over="ignore"):
+        for b in range(args.blocks):
+            i = np.arange(b * n, (b + 1) * n, dtype=np.uint64)
+            entity = (1000 + (i // np.uint64(64)) % np.uint64(50000)).astype(np.int64)
+            attribute = (sm(0x5EED0005, i) % np.uint64(200)).astype(np.int64)
+            t_ms = (1_700_000_000_000 + i.astype(np.int64) * 1000)
+            value = (sm(0x5EED1005, i) % np.uint64(4000)).astype(np.int64)
+            blocks.append(zb.Block(n, zb.ArrayTable(zb.Struct([
+                ("attribute_id", zb.Int(attribute)), ("entity_id", zb.Int(entity)),
+                ("time", zb.Int(t_ms, "TimeMilliseconds")), ("value", zb.Int(value))]))))
+    t0 = time.perf_counter()
+    img = zb.BinaryFile("{}", blocks).to_bytes()
+    t_write = time.perf_counter() - t0
+    info, arrays = zb.file_index(img)
+    na = info.n_arrays
+    out_bytes = 8 * int(info.total_values)
+    # (i) device-resident: image in HBM, one batched submission
+    dev = torch.device("cuda", 0)
+    d_img = torch.frombuffer(bytearray(img), dtype=torch.uint8).to(dev)
+    outs = [torch.empty(arrays[k].count, dtype=torch.int64, device=dev) for k in range(na)]
+    descs = device.make_descs([(d_img.data_ptr() + arrays[k].offset, arrays[k].len, arrays[k].count, outs[k].data_ptr(), _lib.ELEM_I64)
+                               for k in range(na)])
+    res = device.new_results(na, dev)
+    device.decode_batch_dev(descs, res)
+    torch.cuda.synchronize()
+    rs = device.read_results(res)
+    assert all(r.status == 0 for r in rs)
+    widths = sorted(set(r.width for r in rs))
+    assert np.array_equal(outs[3].cpu().numpy(), blocks[0].table.column.fields[3][1].values)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(10):
+        device.decode_batch_dev(descs, res)
+    e1.record()
+    torch.cuda.synchronize()
+    k_ms = e0.elapsed_time(e1) / 10
+    enc_bytes = sum(arrays[k].len for k in range(na))
+    del outs, d_img
+    # (ii) host image -> host values
+    h_outs = [np.empty(arrays[k].count, dtype=np.int64) for k in range(na)]
+    ptrs = (C.c_void_p * na)(*[o.ctypes.data for o in h_outs])
+    statuses = (C.c_int * na)()
+    buf = np.frombuffer(img, dtype=np.uint8)
+    best = None
+    for _ in range(args.reps + 1):
+        t0 = time.perf_counter()
+        st = _lib.lib.zbra_hip_file_decode(buf.ctypes.data_as(C.c_void_p), buf.size, arrays, na, ptrs, statuses)
+        dt = time.perf_counter() - t0
+        assert st == 0
+        best = dt if best is None or dt < best else best
+    assert np.array_equal(h_outs[-1], blocks[-1].table.column.fields[3][1].values)
+    print(json.dumps({
+        "what": f"full-file configuration, one GPU's file scaled to {args.blocks} Blocks of 2^{args.rows_log2} rows x 4 Int columns "
+                f"({len(img) / 1e9:.2f} GB image, {out_bytes / 1e9:.2f} GB of values; the full configuration is 64 GB per file)",
+        "arrays": int(na), "widths": widths, "write_to_bytes_s": round(t_write, 3),
+        "kernel_only_ms": round(k_ms, 4), "kernel_only_decoded_GBps": round(out_bytes / k_ms / 1e6, 1),
+        "kernel_only_algorithmic_GBps": round((enc_bytes + out_bytes) / k_ms / 1e6, 1),
+        "hbm_frac": round((enc_bytes + out_bytes) / k_ms / 1e6 / 8000, 4),
+        "host_to_host_ms": round(best * 1e3, 2), "host_to_host_decoded_GBps": round(out_bytes / best / 1e9, 2)}))
+
+
+if __name__ == "__main__":
+    main()
