@@ -221,6 +221,14 @@ int zbra_hip_file_index(const uint8_t *image, size_t len, zbra_file_array *array
 int zbra_hip_file_decode(const uint8_t *image, size_t len, const zbra_file_array *arrays, size_t n, void *const *outs,
                          int *statuses);
 
+/* decompress_int_array / read_u32_array_compressed for `nd` arrays whose encoded bytes sit in
+ * separate HOST buffers, as they do after the reference's read_exact into a fresh Vec per array
+ * (binary.rs:648-654, 671-674): descs[i].data / .out are HOST pointers here, out holding
+ * descs[i].count elements of descs[i].kind.  Same pipeline as zbra_hip_file_decode (which is this
+ * call on the arrays of one image).  statuses (may be NULL) receives one zbra_status per array;
+ * the return value is the first non-OK status. */
+int zbra_hip_decode_batch(const zbra_array_desc *descs, size_t nd, int *statuses);
+
 /* The write path's counterpart: int arrays in HOST memory (descs[i].values, .n, .kind; .out and
  * .cap ignored) become frames `u32 count | u32 clen | E` back to back in the HOST buffer `out`,
  * which is what Column::write_to emits for each of them (binary.rs:293-347 through :639-669).

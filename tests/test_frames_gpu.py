@@ -108,3 +108,42 @@ def test_frames_dev_misaligned_with_guards(env):
         rs = device.read_results(res)
         for i, a in enumerate(arrs):
             assert rs[i].status == 0 and rs[i].out_count == offs[i + 1] - offs[i] - 8
+
+
+def test_host_batch_decode_of_scattered_arrays(env):
+    """zbra_hip_decode_batch: compressed arrays in separate host buffers (what read_exact per array
+    leaves behind), mixed kinds and sizes, an empty one, and a corrupted one whose error must not
+    disturb the rest."""
+    _, oc, zc, _, L = env
+    arrs = _mixed_arrays()
+    items = [(oc.compress_int_array(a.astype(np.int64)), a.size, a.dtype) for a in arrs]
+    got = zc.read_int_arrays_compressed(items)
+    for g, a in zip(got, arrs):
+        assert g.dtype == a.dtype and np.array_equal(g, a)
+    # count larger than what was encoded for an empty array: empty result, not an error
+    assert zc.read_int_arrays_compressed([(b"", 7, np.int64)])[0].size == 0
+    bad = list(items)
+    k = next(i for i, it in enumerate(items) if len(it[0]) > 20)
+    e = bytearray(items[k][0])
+    e[8:12] = (len(e)).to_bytes(4, "little")              # packed_len beyond the bytes that are there
+    bad[k] = (bytes(e), items[k][1], items[k][2])
+    with pytest.raises(zc.DecompressionError, match="Insufficient data"):
+        zc.read_int_arrays_compressed(bad)
+    # the C call reports per-array statuses and still decodes the others
+    descs = (L.ArrayDesc * len(bad))()
+    keep, outs = [], []
+    for i, (data, count, dtype) in enumerate(bad):
+        d = np.frombuffer(data, dtype=np.uint8)
+        o = np.full(count, 77, dtype=dtype)
+        keep.append(d); outs.append(o)
+        descs[i].data = d.ctypes.data if d.size else None
+        descs[i].len = d.size; descs[i].count = count
+        descs[i].out = o.ctypes.data if o.size else None
+        descs[i].kind = L.ELEM_U32 if o.dtype == np.uint32 else L.ELEM_I64
+    statuses = (C.c_int * len(bad))()
+    st = L.lib.zbra_hip_decode_batch(descs, len(bad), statuses)
+    assert st == L.ERR_SHORT_PACKED and statuses[k] == L.ERR_SHORT_PACKED and sum(1 for s in statuses if s) == 1
+    assert (outs[k] == 77).all()
+    for i, a in enumerate(arrs):
+        if i != k:
+            assert np.array_equal(outs[i], a), i

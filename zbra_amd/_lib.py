@@ -67,6 +67,7 @@ SIGNATURES = {
     "zbra_hip_decode_batch_dev": (C.c_int, [C.POINTER(ArrayDesc), _sz, _p, _p]),
     "zbra_hip_encode_dev": (C.c_int, [_p, _sz, C.c_uint32, _p, _sz, _p, _p]),
     "zbra_hip_encode_batch_dev": (C.c_int, [C.POINTER(EncodeDesc), _sz, _p, _p]),
+    "zbra_hip_decode_batch": (C.c_int, [C.POINTER(ArrayDesc), _sz, C.POINTER(C.c_int)]),
     "zbra_hip_encode_frames_dev": (C.c_int, [C.POINTER(EncodeDesc), _sz, _p, _sz, _p, _p, _p]),
     "zbra_hip_encode_frames": (C.c_int, [C.POINTER(EncodeDesc), _sz, _p, _sz, C.POINTER(C.c_uint64), C.POINTER(C.c_int)]),
     "zbra_hip_file_index": (C.c_int, [_p, _sz, C.POINTER(FileArray), _sz, C.POINTER(FileInfo), _psz]),

@@ -182,3 +182,31 @@ def write_int_arrays_compressed(arrays, as_bytes=True):
         _raise(st)
     offs = np.frombuffer(offsets, dtype=np.uint64).astype(np.int64)
     return (out[: offs[n]].tobytes() if as_bytes else out[: offs[n]]), offs
+
+
+def read_int_arrays_compressed(arrays):
+    """read_int_array_compressed / read_u32_array_compressed (binary.rs:648-654, 671-674) for a
+    list of (compressed bytes, count, dtype) in one submission: the compressed arrays sit in
+    separate host buffers, as after the reference's read_exact per array.  dtype is np.int64 or
+    np.uint32 (enum tags).  Returns the list of decoded numpy arrays; raises on the first array
+    the reference would reject."""
+    from ._lib import ELEM_I64, ELEM_U32, ArrayDesc
+    n = len(arrays)
+    descs = (ArrayDesc * max(1, n))()
+    keep, outs = [], []
+    for i, (data, count, dtype) in enumerate(arrays):
+        d = _bytes_arr(data)
+        out = np.empty(count, dtype=np.uint32 if np.dtype(dtype) == np.uint32 else np.int64)
+        keep.append(d)
+        outs.append(out)
+        descs[i].data = d.ctypes.data if d.size else None
+        descs[i].len = d.size
+        descs[i].count = count
+        descs[i].out = out.ctypes.data if out.size else None
+        descs[i].kind = ELEM_U32 if out.dtype == np.uint32 else ELEM_I64
+    statuses = (C.c_int * max(1, n))()
+    st = lib.zbra_hip_decode_batch(descs, n, statuses)
+    if st:
+        _raise(st)
+    # decompress_int_array returns an empty Vec for empty data whatever count says
+    return [o[:0] if k.size == 0 else o for o, k in zip(outs, keep)]

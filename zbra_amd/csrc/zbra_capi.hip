@@ -487,6 +487,119 @@ static int stage_host(const void *in, size_t in_bytes, void *out, size_t out_byt
     return ZBRA_OK;
 }
 
+// ---- many arrays, host memory both ends -----------------------------------------------------
+
+// items[i]: E in HOST memory (data, len), count, kind, and the HOST buffer the values go to.  The
+// decoded values of up to MAX_OUT bytes of arrays ("a round") share one device buffer that a
+// single pipelined copy takes back to the callers' buffers.  Inside a round, groups of consecutive
+// arrays (bounded encoded bytes) are gathered up and batch-decoded on two alternating lanes just
+// ahead of that copy: upload, kernels and the way back overlap, and the copy never drains between
+// groups.
+static int decode_host_batch(const zbra_array_desc *items, size_t n, int *statuses) {
+    for (size_t i = 0; i < n; i++) {
+        if (items[i].count > MAX_COUNT || items[i].kind > ZBRA_ELEM_U32) return ZBRA_ERR_INVALID_ARG;
+        if ((items[i].len && !items[i].data) || (items[i].count && items[i].len && !items[i].out)) return ZBRA_ERR_INVALID_ARG;
+    }
+    DeviceCtx *ctx;
+    ZBRA_TRY(current_ctx(&ctx));
+    std::lock_guard<std::mutex> g(ctx->host_mu);
+    ZBRA_TRY(ctx->ensure_file_lanes());
+    if (!ctx->stream2) ZBRA_HIP_TRY(hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking));
+    for (hipEvent_t &e : ctx->piece_done)
+        if (!e) ZBRA_HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    constexpr size_t MAX_IN = (size_t)16 << 20, MAX_OUT = (size_t)4 << 30, MAX_ARRAYS = 4096;
+    struct Group { size_t first, end, in_bytes, out_off, out_end; };
+    // status words come back into pinned memory: a copy into pageable memory would block the
+    // host until the group's kernels have run, and the host has the copy back to keep fed
+    ZBRA_TRY(DeviceCtx::grow_pinned(ctx->pin_res, n * sizeof(zbra_dev_result)));
+    zbra_dev_result *results = (zbra_dev_result *)ctx->pin_res.ptr;
+    std::vector<zbra_array_desc> descs;
+    std::vector<HostPipe::Segment> segs, up;
+    std::vector<Group> groups;
+    std::vector<size_t> out_off(n);
+    auto padded_out = [&](size_t k) { return (size_t)((items[k].count * (items[k].kind == ZBRA_ELEM_I64 ? 8 : 4) + 15) / 16 * 16); };
+    auto padded_in = [&](size_t k) { return (size_t)((items[k].len + 15) / 16 * 16); };
+    int st = ZBRA_OK;
+    for (size_t r0 = 0; r0 < n && st == ZBRA_OK;) {
+        // ---- one round: arrays [r0, r1) ----
+        size_t r1 = r0, total = 0;
+        groups.clear();
+        while (r1 < n && (r1 == r0 || total + padded_out(r1) <= MAX_OUT)) {
+            Group gr{r1, r1, 0, total, total};
+            while (r1 < n && r1 - gr.first < MAX_ARRAYS) {
+                const size_t ib = padded_in(r1), ob = padded_out(r1);
+                if (r1 > gr.first && (gr.in_bytes + ib > MAX_IN || total + ob > MAX_OUT)) break;
+                out_off[r1] = total;
+                total += ob;
+                gr.in_bytes += ib;
+                r1++;
+            }
+            gr.end = r1;
+            gr.out_end = total;
+            groups.push_back(gr);
+        }
+        ZBRA_TRY(DeviceCtx::grow_dev(ctx->dev_out, total + 16));
+        // what goes back: exactly the values each array produces, known from its header, which the
+        // host can read (nothing for empty / rejected arrays)
+        segs.clear();
+        for (size_t k = r0; k < r1; k++) {
+            size_t produced = 0;
+            if (host_check_decode(items[k].data, items[k].len, items[k].count, &produced) == ZBRA_OK && produced)
+                segs.push_back({out_off[k], items[k].out, produced * (items[k].kind == ZBRA_ELEM_I64 ? 8 : 4)});
+        }
+        size_t submitted = 0, waited = 0;
+        auto submit = [&]() -> int {  // upload + decode of the next group, on its lane
+            const Group &gr = groups[submitted];
+            FileLane &lane = ctx->file_lanes[submitted & 1];
+            const size_t ng = gr.end - gr.first;
+            if (lane.img.cap < gr.in_bytes + 16 || lane.res.cap < ng * sizeof(zbra_dev_result)) {
+                ZBRA_HIP_TRY(hipStreamSynchronize(lane.stream));  // a kernel may still read the old buffers
+                ZBRA_TRY(DeviceCtx::grow_dev(lane.img, gr.in_bytes + 16));
+                ZBRA_TRY(DeviceCtx::grow_dev(lane.res, ng * sizeof(zbra_dev_result)));
+            }
+            descs.resize(ng);
+            up.clear();
+            size_t o = 0;
+            for (size_t k = 0; k < ng; k++) {
+                const zbra_array_desc &it = items[gr.first + k];
+                if (it.len) up.push_back({o, const_cast<uint8_t *>(it.data), (size_t)it.len});
+                descs[k].data = (const uint8_t *)lane.img.ptr + o;
+                descs[k].len = it.len; descs[k].count = it.count; descs[k].out = (char *)ctx->dev_out.ptr + out_off[gr.first + k];
+                descs[k].kind = it.kind; descs[k].reserved = 0;
+                o += padded_in(gr.first + k);
+            }
+            ZBRA_TRY(ctx->pipe_up.to_device_segments(up.data(), up.size(), lane.img.ptr, gr.in_bytes, lane.stream));
+            ZBRA_TRY(decode_batch_dev(ctx, descs.data(), ng, (zbra_dev_result *)lane.res.ptr, lane.stream));
+            ZBRA_HIP_TRY(hipMemcpyAsync(&results[gr.first], lane.res.ptr, ng * sizeof(zbra_dev_result), hipMemcpyDeviceToHost, lane.stream));
+            ZBRA_HIP_TRY(hipEventRecord(ctx->piece_done[submitted % 4], lane.stream));
+            submitted++;
+            return ZBRA_OK;
+        };
+        st = ctx->pipe.to_host_segments(segs.data(), segs.size(), ctx->dev_out.ptr, total, ctx->stream2, [&](size_t last_byte) -> int {
+            // groups that produce bytes below last_byte must have been enqueued; keep one more in flight
+            size_t need = waited;
+            while (need < groups.size() && groups[need].out_off < last_byte) need++;
+            while (submitted < groups.size() && submitted < need + 1) ZBRA_TRY(submit());
+            for (; waited < need; waited++) ZBRA_HIP_TRY(hipStreamWaitEvent(ctx->stream2, ctx->piece_done[waited % 4], 0));
+            return ZBRA_OK;
+        });
+        // groups whose arrays produce nothing are still decoded for their status words
+        while (st == ZBRA_OK && submitted < groups.size()) st = submit();
+        const int st0 = hip_status(hipStreamSynchronize(ctx->file_lanes[0].stream));
+        const int st1 = hip_status(hipStreamSynchronize(ctx->file_lanes[1].stream));
+        const int st2 = hip_status(hipStreamSynchronize(ctx->stream2));
+        if (st == ZBRA_OK) st = st0 != ZBRA_OK ? st0 : st1 != ZBRA_OK ? st1 : st2;
+        r0 = r1;
+    }
+    if (st != ZBRA_OK) return st;
+    int first_err = ZBRA_OK;
+    for (size_t k = 0; k < n; k++) {
+        if (statuses) statuses[k] = (int)results[k].status;
+        if (results[k].status != ZBRA_OK && first_err == ZBRA_OK) first_err = (int)results[k].status;
+    }
+    return first_err;
+}
+
 }  // namespace zbra
 
 using namespace zbra;
@@ -787,110 +900,20 @@ int zbra_hip_file_decode(const uint8_t *image, size_t len, const zbra_file_array
                          int *statuses) {
     if (n == 0) return ZBRA_OK;
     if (!image || !arrays || !outs) return ZBRA_ERR_INVALID_ARG;
+    std::vector<zbra_array_desc> items(n);
     for (size_t i = 0; i < n; i++) {
         if (arrays[i].offset > len || arrays[i].len > len - arrays[i].offset) return ZBRA_ERR_INVALID_ARG;
-        if (arrays[i].count > MAX_COUNT || arrays[i].kind > ZBRA_ELEM_U32) return ZBRA_ERR_INVALID_ARG;
-        if (arrays[i].count && arrays[i].len && !outs[i]) return ZBRA_ERR_INVALID_ARG;
         if (i && arrays[i].offset < arrays[i - 1].offset + arrays[i - 1].len) return ZBRA_ERR_INVALID_ARG;  // file order
+        items[i].data = image + arrays[i].offset; items[i].len = arrays[i].len; items[i].count = arrays[i].count;
+        items[i].out = outs[i]; items[i].kind = arrays[i].kind; items[i].reserved = 0;
     }
-    DeviceCtx *ctx;
-    ZBRA_TRY(current_ctx(&ctx));
-    std::lock_guard<std::mutex> g(ctx->host_mu);
-    ZBRA_TRY(ctx->ensure_file_lanes());
-    if (!ctx->stream2) ZBRA_HIP_TRY(hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking));
-    for (hipEvent_t &e : ctx->piece_done)
-        if (!e) ZBRA_HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-    // The decoded values of up to MAX_OUT bytes of arrays ("a round") share one device buffer that
-    // a single pipelined copy takes back to the caller's arrays.  Inside a round, groups of
-    // consecutive arrays (bounded image span) are uploaded and decoded on two alternating lanes
-    // just ahead of the copy: upload, kernels and the way back overlap, and the copy never drains
-    // between groups.
-    constexpr size_t MAX_SPAN = (size_t)16 << 20, MAX_OUT = (size_t)4 << 30, MAX_ARRAYS = 4096;
-    struct Group { size_t first, end, lo, hi, out_off, out_end; };
-    // status words come back into pinned memory: a copy into pageable memory would block the
-    // host until the group's kernels have run, and the host has the copy back to keep fed
-    ZBRA_TRY(DeviceCtx::grow_pinned(ctx->pin_res, n * sizeof(zbra_dev_result)));
-    zbra_dev_result *results = (zbra_dev_result *)ctx->pin_res.ptr;
-    std::vector<zbra_array_desc> descs;
-    std::vector<HostPipe::Segment> segs;
-    std::vector<Group> groups;
-    std::vector<size_t> out_off(n);
-    auto padded = [&](size_t k) { return (size_t)((arrays[k].count * (arrays[k].kind == ZBRA_ELEM_I64 ? 8 : 4) + 15) / 16 * 16); };
-    int st = ZBRA_OK;
-    for (size_t r0 = 0; r0 < n && st == ZBRA_OK;) {
-        // ---- one round: arrays [r0, r1) ----
-        size_t r1 = r0, total = 0;
-        groups.clear();
-        while (r1 < n && (r1 == r0 || total + padded(r1) <= MAX_OUT)) {
-            Group gr{r1, r1, arrays[r1].offset, arrays[r1].offset, total, total};
-            while (r1 < n && r1 - gr.first < MAX_ARRAYS) {
-                const size_t h = arrays[r1].offset + arrays[r1].len, ob = padded(r1);
-                if (r1 > gr.first && (h - gr.lo > MAX_SPAN || total + ob > MAX_OUT)) break;
-                out_off[r1] = total;
-                total += ob;
-                gr.hi = h;
-                r1++;
-            }
-            gr.end = r1;
-            gr.out_end = total;
-            groups.push_back(gr);
-        }
-        ZBRA_TRY(DeviceCtx::grow_dev(ctx->dev_out, total + 16));
-        // what goes back: exactly the values each array produces, known from its header, which the
-        // host can read in the image (nothing for empty / rejected arrays)
-        segs.clear();
-        for (size_t k = r0; k < r1; k++) {
-            size_t produced = 0;
-            if (host_check_decode(image + arrays[k].offset, arrays[k].len, arrays[k].count, &produced) == ZBRA_OK && produced)
-                segs.push_back({out_off[k], outs[k], produced * (arrays[k].kind == ZBRA_ELEM_I64 ? 8 : 4)});
-        }
-        size_t submitted = 0, waited = 0;
-        auto submit = [&]() -> int {  // upload + decode of the next group, on its lane
-            const Group &gr = groups[submitted];
-            FileLane &lane = ctx->file_lanes[submitted & 1];
-            const size_t span = gr.hi - gr.lo, ng = gr.end - gr.first;
-            if (lane.img.cap < span + 16 || lane.res.cap < ng * sizeof(zbra_dev_result)) {
-                ZBRA_HIP_TRY(hipStreamSynchronize(lane.stream));  // a kernel may still read the old buffers
-                ZBRA_TRY(DeviceCtx::grow_dev(lane.img, span + 16));
-                ZBRA_TRY(DeviceCtx::grow_dev(lane.res, ng * sizeof(zbra_dev_result)));
-            }
-            ZBRA_TRY(ctx->pipe_up.to_device(lane.img.ptr, image + gr.lo, span, lane.stream));
-            descs.resize(ng);
-            for (size_t k = 0; k < ng; k++) {
-                const zbra_file_array &a = arrays[gr.first + k];
-                descs[k].data = (const uint8_t *)lane.img.ptr + (a.offset - gr.lo);
-                descs[k].len = a.len; descs[k].count = a.count; descs[k].out = (char *)ctx->dev_out.ptr + out_off[gr.first + k];
-                descs[k].kind = a.kind; descs[k].reserved = 0;
-            }
-            ZBRA_TRY(decode_batch_dev(ctx, descs.data(), ng, (zbra_dev_result *)lane.res.ptr, lane.stream));
-            ZBRA_HIP_TRY(hipMemcpyAsync(&results[gr.first], lane.res.ptr, ng * sizeof(zbra_dev_result), hipMemcpyDeviceToHost, lane.stream));
-            ZBRA_HIP_TRY(hipEventRecord(ctx->piece_done[submitted % 4], lane.stream));
-            submitted++;
-            return ZBRA_OK;
-        };
-        st = ctx->pipe.to_host_segments(segs.data(), segs.size(), ctx->dev_out.ptr, total, ctx->stream2, [&](size_t last_byte) -> int {
-            // groups that produce bytes below last_byte must have been enqueued; keep one more in flight
-            size_t need = waited;
-            while (need < groups.size() && groups[need].out_off < last_byte) need++;
-            while (submitted < groups.size() && submitted < need + 1) ZBRA_TRY(submit());
-            for (; waited < need; waited++) ZBRA_HIP_TRY(hipStreamWaitEvent(ctx->stream2, ctx->piece_done[waited % 4], 0));
-            return ZBRA_OK;
-        });
-        // groups whose arrays produce nothing are still decoded for their status words
-        while (st == ZBRA_OK && submitted < groups.size()) st = submit();
-        const int st0 = hip_status(hipStreamSynchronize(ctx->file_lanes[0].stream));
-        const int st1 = hip_status(hipStreamSynchronize(ctx->file_lanes[1].stream));
-        const int st2 = hip_status(hipStreamSynchronize(ctx->stream2));
-        if (st == ZBRA_OK) st = st0 != ZBRA_OK ? st0 : st1 != ZBRA_OK ? st1 : st2;
-        r0 = r1;
-    }
-    if (st != ZBRA_OK) return st;
-    int first_err = ZBRA_OK;
-    for (size_t k = 0; k < n; k++) {
-        if (statuses) statuses[k] = (int)results[k].status;
-        if (results[k].status != ZBRA_OK && first_err == ZBRA_OK) first_err = (int)results[k].status;
-    }
-    return first_err;
+    return decode_host_batch(items.data(), n, statuses);
+}
+
+int zbra_hip_decode_batch(const zbra_array_desc *descs, size_t nd, int *statuses) {
+    if (nd == 0) return ZBRA_OK;
+    if (!descs) return ZBRA_ERR_INVALID_ARG;
+    return decode_host_batch(descs, nd, statuses);
 }
 
 }  // extern "C"
