@@ -1,0 +1,31 @@
+#!/usr/bin/env python3
+"""Encodes one device-resident column a few times (run it under rocprofv3 --kernel-trace --stats to
+see the per-kernel times).  Usage: enc_kernels.py narrow|wide|w40|full [rows_log2]"""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+
+from zbra_amd import device
+
+kind = sys.argv[1] if len(sys.argv) > 1 else "w40"
+n = 1 << (int(sys.argv[2]) if len(sys.argv) > 2 else 27)
+dev = torch.device("cuda", 0)
+g = torch.Generator(device=dev)
+g.manual_seed(3)
+if kind == "narrow":
+    v = 1_700_000_000_000 + torch.randint(0, 4000, (n,), dtype=torch.int64, device=dev, generator=g)
+elif kind == "wide":
+    v = torch.randint(-(1 << 24), 1 << 24, (n,), dtype=torch.int64, device=dev, generator=g)
+elif kind == "w40":
+    v = torch.randint(-(1 << 38), 1 << 38, (n,), dtype=torch.int64, device=dev, generator=g)
+else:
+    v = torch.randint(-(1 << 62), 1 << 62, (n,), dtype=torch.int64, device=dev, generator=g)
+out = torch.empty(device.encode_bound(n), dtype=torch.uint8, device=dev)
+res = device.new_results(1, dev)
+for _ in range(5):
+    device.encode_dev(v, out, res)
+torch.cuda.synchronize()
+r = device.read_results(res)[0]
+print(kind, "n", n, "width", r.width, "bytes", r.out_count)

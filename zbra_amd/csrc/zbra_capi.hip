@@ -284,6 +284,11 @@ static int encode_batch_dev(DeviceCtx *ctx, const EncodeItem *items, size_t nd, 
         const unsigned ga = (unsigned)((nd + 255) / 256);
         // workgroups per listed array in the select passes: about 4096 in all, at least 8 each
         const uint32_t per_array = n_list ? (n_list >= 512 ? 8u : 4096u / n_list) : 1u;
+        // Tiles a select-pass workgroup reads before it merges its 4096 counters into the array's
+        // histogram (device-scope atomics).  One 2^27-value array with a wide bracket: a real pass
+        // takes 142 us at 1.5 tiles per workgroup (4096 workgroups), 62 us at 4, 44 us at 16, 115 us
+        // at 64; a thousand arrays keep all their workgroups busy at 4 and slow down beyond.
+        const uint32_t hist_tiles_per_wg = n_list <= 4 ? 16u : 4u;
         if (ntiles) {
             hipLaunchKernelGGL(enc_sample_kernel, dim3((unsigned)nd), dim3(SAMPLE_THREADS), 0, stream, d_jobs, (uint32_t)nd,
                                bracket ? 1u : 0u);
@@ -297,7 +302,7 @@ static int encode_batch_dev(DeviceCtx *ctx, const EncodeItem *items, size_t nd, 
         if (ntiles) {
             for (uint32_t pass = 0; n_list && pass < (uint32_t)MAX_PASSES; pass++) {
                 hipLaunchKernelGGL(enc_hist_kernel, dim3(n_list * per_array), dim3(THREADS), 0, stream, d_jobs, d_list, n_list,
-                                   per_array, d_hist, pass);
+                                   per_array, hist_tiles_per_wg, d_hist, pass);
                 hipLaunchKernelGGL(enc_select_kernel, dim3((unsigned)nd), dim3(THREADS), 0, stream, d_jobs, d_hist, pass);
             }
             if (mode == ENCODE_FULL)

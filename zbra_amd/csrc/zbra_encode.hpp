@@ -525,7 +525,7 @@ __device__ __forceinline__ void hist_key(uint32_t *lh, uint64_t key, uint32_t pa
 // w, w + per_array, ... of array list[i], so an array that needs many passes is never left to the
 // two or three workgroups that happen to own its stretch of the submission.
 __global__ __launch_bounds__(THREADS) void enc_hist_kernel(EncodeJob *__restrict__ jobs, const uint32_t *__restrict__ list,
-                                                            uint32_t n_list, uint32_t per_array,
+                                                            uint32_t n_list, uint32_t per_array, uint32_t tiles_per_wg,
                                                             uint32_t *__restrict__ hist, uint32_t pass) {
     const uint32_t li = blockIdx.x / per_array, w = blockIdx.x % per_array;
     if (li >= n_list) return;
@@ -533,6 +533,13 @@ __global__ __launch_bounds__(THREADS) void enc_hist_kernel(EncodeJob *__restrict
     const EncodeJob &job = jobs[a];
     const uint32_t mode = job.mode;
     if ((mode != SEL_FULL && mode != SEL_BRACKET_COMPACT) || pass >= job.passes) return;
+    // Every workgroup that takes part merges up to BINS counters into the array's histogram with
+    // device-scope atomics, which cost more than reading a tile: only as many workgroups take part
+    // as have tiles_per_wg tiles each (a candidate list holds job.inb values).
+    const uint64_t work_tiles = ((mode == SEL_FULL ? job.n : job.inb) + TILE - 1) / TILE;
+    const uint64_t want = work_tiles / tiles_per_wg;
+    const uint32_t eff = want < 1 ? 1u : want < per_array ? (uint32_t)want : per_array;
+    if (w >= eff) return;
     __shared__ uint32_t lh[BINS];
     for (uint32_t b = threadIdx.x; b < BINS; b += THREADS) lh[b] = 0;
     __syncthreads();
@@ -544,7 +551,7 @@ __global__ __launch_bounds__(THREADS) void enc_hist_kernel(EncodeJob *__restrict
         const void *values = job.values;
         const uint32_t kind = job.kind;
         const uint64_t n = job.n;
-        for (uint64_t v0 = (uint64_t)w * TILE; v0 < n; v0 += (uint64_t)per_array * TILE) {
+        for (uint64_t v0 = (uint64_t)w * TILE; v0 < n; v0 += (uint64_t)eff * TILE) {
             int64_t x[2 * PAIRS];
             load_tile_from(values, kind, v0, n, 0, x);
 #pragma unroll
@@ -555,7 +562,7 @@ __global__ __launch_bounds__(THREADS) void enc_hist_kernel(EncodeJob *__restrict
         }
     } else {
         const uint64_t seg_cap = job.seg_cap, seg_tiles = seg_cap / TILE;
-        for (uint64_t u = w; u < seg_tiles * CAND_SEGS; u += per_array) {
+        for (uint64_t u = w; u < seg_tiles * CAND_SEGS; u += eff) {
             const uint64_t sgm = u % CAND_SEGS, v0 = sgm * seg_cap + (u / CAND_SEGS) * TILE;
             const uint64_t end = sgm * seg_cap + job.counters->slot[sgm].cand_count;  // values exist below this index
             if (v0 >= end) continue;
