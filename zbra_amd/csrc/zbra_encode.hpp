@@ -322,9 +322,13 @@ __device__ __forceinline__ void bracket_values(const int64_t (&x)[2 * PAIRS], ui
             acc.above = is_above && b < acc.above ? b : acc.above;
             if (MODE == SEL_BRACKET_MICRO) {
                 if (inside) lh[((uint32_t)(b - lo_b) & (MICRO_KEYS - 1)) * THREADS + threadIdx.x] += 1u;
+            } else if (MODE == SEL_BRACKET_COMPACT) {
+                // wave-private staging: the ballot gives every lane its slot, no atomic, no barrier
+                const uint64_t m = __ballot(inside);
+                if (inside) lcand[*lcount + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u))] = x[e];
+                *lcount += (uint32_t)__popcll(m);
             } else if (inside) {
-                if (MODE == SEL_BRACKET_HIST) atomicAdd(&lh[(uint32_t)(b - lo_b)], 1u);
-                else lcand[atomicAdd(lcount, 1u)] = x[e];
+                atomicAdd(&lh[(uint32_t)(b - lo_b)], 1u);
             }
         }
     }
@@ -339,11 +343,9 @@ __global__ __launch_bounds__(THREADS) void enc_bracket_kernel(EncodeJob *__restr
     static_assert(sizeof(int64_t) * CAND_LDS >= sizeof(uint32_t) * BINS && CAND_LDS >= TILE, "LDS pool too small");
     uint32_t *lh = (uint32_t *)pool;
     int64_t *lcand = pool;
-    __shared__ uint32_t lcount;                 // candidates staged in lcand
     __shared__ unsigned long long lbelow, linb; // this run's counts
-    __shared__ unsigned long long lbase;        // where a flush goes in the global list
     for (uint32_t b = threadIdx.x; b < BINS; b += THREADS) lh[b] = 0;
-    if (threadIdx.x == 0) { lcount = 0; lbelow = 0; linb = 0; }
+    if (threadIdx.x == 0) { lbelow = 0; linb = 0; }
     __syncthreads();
     for_each_array_run(tile_start, nd, ntiles, [&](uint32_t a, uint64_t a_first, uint64_t t0, uint64_t t1) {
         const EncodeJob &job = jobs[a];
@@ -360,23 +362,32 @@ __global__ __launch_bounds__(THREADS) void enc_bracket_kernel(EncodeJob *__restr
         const uint64_t lo_b = job.lo_b, hi_b = job.hi_b;
         const int64_t fill = load_value(job, 0);  // a value of the array: a no-op for min and max
         BracketAcc acc;
-        auto flush_candidates = [&]() {  // all lanes; lcount candidates -> global list
-            __syncthreads();
-            const uint32_t cnt = lcount;
-            if (cnt) {
-                const uint32_t sgm = (blockIdx.x + flushes++) % CAND_SEGS;
-                if (threadIdx.x == 0)
-                    lbase = atomicAdd(&job.counters->slot[sgm].cand_count, (unsigned long long)cnt);
-                __syncthreads();
-                const uint64_t base = lbase;
-                if (base + cnt <= seg_cap) {
-                    ZBRA_GLOBAL int64_t *dst = gptr_mut<int64_t>(job.cand) + (size_t)sgm * seg_cap + base;
-                    for (uint32_t i = threadIdx.x; i < cnt; i += THREADS) dst[i] = lcand[i];
-                }
-                __syncthreads();
-                if (threadIdx.x == 0) lcount = 0;
-                __syncthreads();
+        // Candidates are staged per WAVE: a quarter of the pool each, filled in ballot order and
+        // flushed (one returning atomic on the segment's counter, then a copy by the wave's 64
+        // lanes) when less than half a tile's worth of room is left.  No lane of another wave is
+        // involved, so the tile loop has no workgroup barrier.
+        constexpr uint32_t WAVES = THREADS / 64, WAVE_CAP = CAND_LDS / WAVES;
+        static_assert(WAVE_CAP >= 2 * (TILE / 2 / WAVES), "a wave appends at most TILE / 2 / WAVES values between two looks");
+        const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+        int64_t *wstage = lcand + wave * WAVE_CAP;
+        uint32_t wcount = 0;  // uniform within the wave
+        auto flush_wave = [&]() {
+            if (wcount == 0) return;
+            const uint32_t sgm = (blockIdx.x * WAVES + wave + flushes++) % CAND_SEGS;
+            unsigned long long base = 0;
+            if (lane == 0) base = atomicAdd(&job.counters->slot[sgm].cand_count, (unsigned long long)wcount);
+            base = __shfl(base, 0);
+            // the wave's own LDS writes, read back by other lanes of the same wave
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            if (base + wcount <= seg_cap) {
+                ZBRA_GLOBAL int64_t *dst = gptr_mut<int64_t>(job.cand) + (size_t)sgm * seg_cap + base;
+                for (uint32_t i = lane; i < wcount; i += 64) dst[i] = wstage[i];
             }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __builtin_amdgcn_wave_barrier();
+            wcount = 0;
         };
         for (uint64_t t = t0; t < t1; ++t) {
             const uint64_t v0 = (t - a_first) * TILE;
@@ -384,31 +395,21 @@ __global__ __launch_bounds__(THREADS) void enc_bracket_kernel(EncodeJob *__restr
             int64_t x[2 * PAIRS];
             load_tile_from(values, kind, v0, n, fill, x);
             if (mode == SEL_BRACKET_HIST) {
-                if (whole) bracket_values<SEL_BRACKET_HIST, true, 0, 2 * PAIRS>(x, v0, n, lo_b, hi_b, acc, lh, lcand, &lcount);
-                else bracket_values<SEL_BRACKET_HIST, false, 0, 2 * PAIRS>(x, v0, n, lo_b, hi_b, acc, lh, lcand, &lcount);
+                if (whole) bracket_values<SEL_BRACKET_HIST, true, 0, 2 * PAIRS>(x, v0, n, lo_b, hi_b, acc, lh, nullptr, nullptr);
+                else bracket_values<SEL_BRACKET_HIST, false, 0, 2 * PAIRS>(x, v0, n, lo_b, hi_b, acc, lh, nullptr, nullptr);
             } else if (mode == SEL_FULL) {
-                bracket_values<SEL_FULL, true, 0, 2 * PAIRS>(x, v0, n, lo_b, hi_b, acc, lh, lcand, &lcount);
+                bracket_values<SEL_FULL, true, 0, 2 * PAIRS>(x, v0, n, lo_b, hi_b, acc, lh, nullptr, nullptr);
             } else if (mode == SEL_BRACKET_MICRO) {
-                if (whole) bracket_values<SEL_BRACKET_MICRO, true, 0, 2 * PAIRS>(x, v0, n, lo_b, hi_b, acc, lh, lcand, &lcount);
-                else bracket_values<SEL_BRACKET_MICRO, false, 0, 2 * PAIRS>(x, v0, n, lo_b, hi_b, acc, lh, lcand, &lcount);
+                if (whole) bracket_values<SEL_BRACKET_MICRO, true, 0, 2 * PAIRS>(x, v0, n, lo_b, hi_b, acc, lh, nullptr, nullptr);
+                else bracket_values<SEL_BRACKET_MICRO, false, 0, 2 * PAIRS>(x, v0, n, lo_b, hi_b, acc, lh, nullptr, nullptr);
             } else {
-                // The LDS list takes half a tile's worth of appends between two looks at its fill.
-                // Every lane must take the same decision (the flush has barriers inside): the fill
-                // is read between two barriers, after the last append of the previous half and
-                // before the first of the next, so no lane can see a count another lane has
-                // already moved on from.
-                __syncthreads();
-                uint32_t staged = lcount;
-                __syncthreads();
-                if (staged + TILE / 2 > (uint32_t)CAND_LDS) flush_candidates();
-                if (whole) bracket_values<SEL_BRACKET_COMPACT, true, 0, PAIRS>(x, v0, n, lo_b, hi_b, acc, lh, lcand, &lcount);
-                else bracket_values<SEL_BRACKET_COMPACT, false, 0, PAIRS>(x, v0, n, lo_b, hi_b, acc, lh, lcand, &lcount);
-                __syncthreads();
-                staged = lcount;
-                __syncthreads();
-                if (staged + TILE / 2 > (uint32_t)CAND_LDS) flush_candidates();
-                if (whole) bracket_values<SEL_BRACKET_COMPACT, true, PAIRS, 2 * PAIRS>(x, v0, n, lo_b, hi_b, acc, lh, lcand, &lcount);
-                else bracket_values<SEL_BRACKET_COMPACT, false, PAIRS, 2 * PAIRS>(x, v0, n, lo_b, hi_b, acc, lh, lcand, &lcount);
+                // a wave appends at most TILE / 2 / WAVES values per half tile
+                if (wcount + TILE / 2 / WAVES > WAVE_CAP) flush_wave();
+                if (whole) bracket_values<SEL_BRACKET_COMPACT, true, 0, PAIRS>(x, v0, n, lo_b, hi_b, acc, lh, wstage, &wcount);
+                else bracket_values<SEL_BRACKET_COMPACT, false, 0, PAIRS>(x, v0, n, lo_b, hi_b, acc, lh, wstage, &wcount);
+                if (wcount + TILE / 2 / WAVES > WAVE_CAP) flush_wave();
+                if (whole) bracket_values<SEL_BRACKET_COMPACT, true, PAIRS, 2 * PAIRS>(x, v0, n, lo_b, hi_b, acc, lh, wstage, &wcount);
+                else bracket_values<SEL_BRACKET_COMPACT, false, PAIRS, 2 * PAIRS>(x, v0, n, lo_b, hi_b, acc, lh, wstage, &wcount);
             }
         }
         // min / max: most waves cannot improve on what is already there: look before queueing an
@@ -428,7 +429,8 @@ __global__ __launch_bounds__(THREADS) void enc_bracket_kernel(EncodeJob *__restr
                 if (above < __hip_atomic_load(pabove, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMin(pabove, (unsigned long long)above);
             }
             if (mode == SEL_BRACKET_COMPACT) {
-                flush_candidates();
+                flush_wave();
+                __syncthreads();  // every wave has emptied its part of the pool
                 for (uint32_t b = threadIdx.x; b < BINS; b += THREADS) lh[b] = 0;  // restore the invariant
             }
             if (mode == SEL_BRACKET_MICRO) {  // sum the lanes' private columns into the array's histogram
