@@ -271,3 +271,36 @@ def test_dev_calls_from_threads_on_own_streams(env):
     for t in ts:
         t.join()
     assert not errs, errs
+
+
+@pytest.mark.parametrize("dtype_name", ["int32", "int64"])
+def test_more_than_2_31_values(env, dtype_name):
+    """One array of 2^31 + 5 values: every value index, bit offset and count beyond 32 bits
+    (`values.len() as u32` allows up to 2^32 - 1, binary.rs:640).  Device-resident, 8 / 16 GiB."""
+    torch, device, _, L = env
+    dt = getattr(torch, dtype_name)
+    n = (1 << 31) + 5
+    v = torch.empty(n, dtype=dt, device="cuda")
+    step = 1 << 28
+    for i0 in range(0, n, step):
+        i1 = min(n, i0 + step)
+        idx = torch.arange(i0, i1, dtype=torch.int64, device="cuda")
+        v[i0:i1] = ((idx * 2654435761) % 1000 + (idx >> 30)).to(dt)   # < 1003: width 10 or 11; the tail differs from the head
+        del idx
+    enc = torch.empty(13 + 2 * n + 64, dtype=torch.uint8, device="cuda")     # far more than 11 bits per value
+    res = device.new_results(1, "cuda")
+    device.encode_dev(v, enc, res)
+    r = device.read_results(res)[0]
+    srt = torch.sort(v[: 1 << 20]).values  # the values are equidistributed: a prefix pins the median well enough to bound it
+    assert r.status == 0 and r.width in (10, 11) and r.out_count == 13 + (n * r.width + 7) // 8
+    assert int(srt[0]) <= r.midpoint <= int(srt[-1]) + 2
+    del srt
+    # exact median: count the values below and above the reported midpoint
+    below = int((v < r.midpoint).sum()); above = int((v > r.midpoint).sum())
+    assert below <= (n - 1) // 2 and above <= n // 2, (below, above)
+    out = torch.empty_like(v)
+    dres = device.new_results(1, "cuda")
+    device.decode_dev(enc, n, out, dres, length=int(r.out_count))
+    d = device.read_results(dres)[0]
+    assert d.status == 0 and d.out_count == n and d.width == r.width
+    assert torch.equal(out, v)
