@@ -79,12 +79,10 @@ static void launch_decode_t(const DecodeConfig &c, unsigned grid, hipStream_t st
 typedef void (*DecodeLauncher)(const DecodeConfig &, unsigned, hipStream_t, const DecodePlan *, const uint64_t *,
                                const uint32_t *, uint32_t, uint64_t);
 struct DecodeShape { int tile, threads; DecodeLauncher fn; };
-static const DecodeShape kDecodeShapes[] = {
-    {2048, 256, launch_decode_t<2048, 256>}, {1024, 256, launch_decode_t<1024, 256>}, {4096, 256, launch_decode_t<4096, 256>},
-    {512, 64, launch_decode_t<512, 64>},     {1024, 64, launch_decode_t<1024, 64>},   {2048, 64, launch_decode_t<2048, 64>},
-    {512, 128, launch_decode_t<512, 128>},   {1024, 128, launch_decode_t<1024, 128>}, {2048, 128, launch_decode_t<2048, 128>},
-    {2048, 512, launch_decode_t<2048, 512>}, {4096, 512, launch_decode_t<4096, 512>}, {1024, 512, launch_decode_t<1024, 512>},
-    {2048, 1024, launch_decode_t<2048, 1024>}, {4096, 1024, launch_decode_t<4096, 1024>},
+static const DecodeShape kDecodeShapes[] = {  // the default and the alternatives it was measured against
+    {2048, 512, launch_decode_t<2048, 512>}, {2048, 256, launch_decode_t<2048, 256>}, {1024, 256, launch_decode_t<1024, 256>},
+    {4096, 512, launch_decode_t<4096, 512>}, {4096, 1024, launch_decode_t<4096, 1024>}, {1024, 128, launch_decode_t<1024, 128>},
+    {512, 64, launch_decode_t<512, 64>},
 };
 
 static DecodeLauncher g_decode_fn = launch_decode_t<2048, 512>;
