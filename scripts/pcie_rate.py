@@ -3,7 +3,7 @@
 pinned host memory.  Blocks of 2^22 rows (the file layout of the full-file configuration) are
 pipelined over two streams: H2D(block k+1) | decode(block k) | D2H(block k-1).
 
-Prints one JSON line; the number goes into DESIGN.md, never into bench.py's `value`."""
+Prints one JSON line (a PCIe-inclusive rate: never bench.py's `value`)."""
 import argparse
 import json
 import os
