@@ -304,3 +304,24 @@ def test_more_than_2_31_values(env, dtype_name):
     d = device.read_results(dres)[0]
     assert d.status == 0 and d.out_count == n and d.width == r.width
     assert torch.equal(out, v)
+
+
+def test_encode_dev_misaligned_inputs(env):
+    """Values that start 8 bytes (int64) or 4 / 8 / 12 bytes (u32 tags) past a 16-byte boundary:
+    the tile loads are 16 bytes per lane and must not care."""
+    torch, device, oc, L = env
+    n = 3 * 2048 + 77
+    big = torch.from_numpy(column("narrow", n + 4, seed=5)).cuda()
+    tags_np = (np.random.default_rng(6).integers(0, 9, n + 4, dtype=np.int64) % 4).astype(np.int32)
+    tags = torch.from_numpy(tags_np).cuda()
+    for v, shifts in ((big, (0, 1)), (tags, (0, 1, 2, 3))):
+        for s in shifts:
+            part = v[s:s + n]
+            assert part.data_ptr() % 16 == (s * v.element_size()) % 16
+            expect = oc.compress_int_array(part.cpu().numpy().astype(np.int64))
+            out = torch.zeros(device.encode_bound(n), dtype=torch.uint8, device="cuda")
+            res = device.new_results(1, "cuda")
+            device.encode_dev(part, out, res)
+            r = device.read_results(res)[0]
+            assert r.status == 0 and r.out_count == len(expect)
+            assert out[: len(expect)].cpu().numpy().tobytes() == expect, (v.dtype, s)

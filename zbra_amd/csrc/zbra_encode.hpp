@@ -102,28 +102,19 @@ __device__ __forceinline__ uint64_t to_stream(const EncodeJob &j, int64_t x, uin
     return j.kind == KIND_U64_PLAIN ? (uint64_t)x : zigzag_encode64((int64_t)((uint64_t)x - mid));
 }
 
-// Loads the two values i, i+1 (i even) of a tile; lanes past the end get `fill`.
-__device__ __forceinline__ void load_pair(const EncodeJob &j, uint64_t i, uint64_t n, int64_t fill, int64_t &x0,
-                                          int64_t &x1) {
-    x0 = fill; x1 = fill;
-    if (i + 1 < n) {
-        if (j.kind != ZBRA_ELEM_U32) {
-            const u64x2 v = *(const ZBRA_GLOBAL u64x2 *)(gptr<int64_t>(j.values) + i);  // 16-B load
-            x0 = (int64_t)v.x; x1 = (int64_t)v.y;
-        } else {
-            const u32x2 v = *(const ZBRA_GLOBAL u32x2 *)(gptr<uint32_t>(j.values) + i);
-            x0 = (int64_t)v.x; x1 = (int64_t)v.y;
-        }
-    } else if (i < n) {
-        x0 = load_value(j, i);
-    }
+constexpr int PAIRS = TILE / (THREADS * 2);  // 16-B loads of int64 per thread per tile
+
+// Which value of its tile a lane holds in x[e]: every load is 16 B per lane, so int64 tiles are
+// dealt in pairs (x[2*it], x[2*it+1] = values it*2*THREADS + 2*tid, +1) and u32 tiles in fours
+// (x[4*q .. 4*q+3] = values q*4*THREADS + 4*tid .. +3).
+__device__ __forceinline__ uint32_t tile_slot(uint32_t kind, int e) {
+    return kind != ZBRA_ELEM_U32 ? (uint32_t)(e >> 1) * THREADS * 2 + threadIdx.x * 2 + (uint32_t)(e & 1)
+                                 : (uint32_t)(e >> 2) * THREADS * 4 + threadIdx.x * 4 + (uint32_t)(e & 3);
 }
 
-constexpr int PAIRS = TILE / (THREADS * 2);  // 16-B loads per thread per tile
-
-// This thread's 2*PAIRS values of the tile that starts at value v0: x[2*it], x[2*it+1] are values
-// v0 + it*2*THREADS + 2*tid (+1).  A tile that lies wholly inside the array issues all its loads
-// back to back; values past n get `fill`.
+// This thread's 2*PAIRS values of the tile that starts at value v0, dealt as tile_slot says.  A
+// tile that lies wholly inside the array issues all its loads back to back; values past n get
+// `fill`.
 __device__ __forceinline__ void load_tile_from(const void *values, uint32_t kind, uint64_t v0, uint64_t n, int64_t fill,
                                                int64_t (&x)[2 * PAIRS]) {
     const uint32_t tid = threadIdx.x;
@@ -136,18 +127,23 @@ __device__ __forceinline__ void load_tile_from(const void *values, uint32_t kind
 #pragma unroll
             for (int it = 0; it < PAIRS; ++it) { x[2 * it] = (int64_t)v[it].x; x[2 * it + 1] = (int64_t)v[it].y; }
         } else {
-            const ZBRA_GLOBAL u32x2 *src = (const ZBRA_GLOBAL u32x2 *)(gptr<uint32_t>(values) + v0) + tid;
-            u32x2 v[PAIRS];
+            static_assert(PAIRS % 2 == 0, "u32 tiles are dealt in fours");
+            const ZBRA_GLOBAL u32x4 *src = (const ZBRA_GLOBAL u32x4 *)(gptr<uint32_t>(values) + v0) + tid;
+            u32x4 v[PAIRS / 2];
 #pragma unroll
-            for (int it = 0; it < PAIRS; ++it) v[it] = __builtin_nontemporal_load(src + it * THREADS);
+            for (int q = 0; q < PAIRS / 2; ++q) v[q] = __builtin_nontemporal_load(src + q * THREADS);
 #pragma unroll
-            for (int it = 0; it < PAIRS; ++it) { x[2 * it] = (int64_t)v[it].x; x[2 * it + 1] = (int64_t)v[it].y; }
+            for (int q = 0; q < PAIRS / 2; ++q) {
+                x[4 * q] = (int64_t)v[q].x; x[4 * q + 1] = (int64_t)v[q].y; x[4 * q + 2] = (int64_t)v[q].z; x[4 * q + 3] = (int64_t)v[q].w;
+            }
         }
     } else {
-        EncodeJob view;
-        view.values = values; view.kind = kind;
 #pragma unroll
-        for (int it = 0; it < PAIRS; ++it) load_pair(view, v0 + it * THREADS * 2 + tid * 2, n, fill, x[2 * it], x[2 * it + 1]);
+        for (int e = 0; e < 2 * PAIRS; ++e) {
+            const uint64_t i = v0 + tile_slot(kind, e);
+            x[e] = fill;
+            if (i < n) x[e] = kind != ZBRA_ELEM_U32 ? gptr<int64_t>(values)[i] : (int64_t)gptr<uint32_t>(values)[i];
+        }
     }
 }
 __device__ __forceinline__ void load_tile(const EncodeJob &j, uint64_t v0, uint64_t n, int64_t fill, int64_t (&x)[2 * PAIRS]) {
@@ -306,7 +302,7 @@ constexpr uint32_t SEL_BRACKET_MICRO = 100;  // template tag only: a histogram-m
 // Values x[E0..E1) of a tile.  MODE and WHOLE (the tile lies wholly inside the array) are
 // compile-time so that the loop body is straight-line code with one branch (the append).
 template <uint32_t MODE, bool WHOLE, int E0, int E1>
-__device__ __forceinline__ void bracket_values(const int64_t (&x)[2 * PAIRS], uint64_t v0, uint64_t n, uint64_t lo_b,
+__device__ __forceinline__ void bracket_values(const int64_t (&x)[2 * PAIRS], uint32_t kind, uint64_t v0, uint64_t n, uint64_t lo_b,
                                                uint64_t hi_b, BracketAcc &acc, uint32_t *lh, int64_t *lcand, uint32_t *lcount) {
 #pragma unroll
     for (int e = E0; e < E1; ++e) {
@@ -314,7 +310,7 @@ __device__ __forceinline__ void bracket_values(const int64_t (&x)[2 * PAIRS], ui
         acc.lo = min(acc.lo, b);  // lanes past the end hold a value of the array: harmless here
         acc.hi = max(acc.hi, b);
         if (MODE != SEL_FULL) {
-            const bool valid = WHOLE || v0 + (e >> 1) * THREADS * 2 + threadIdx.x * 2 + (e & 1) < n;
+            const bool valid = WHOLE || v0 + tile_slot(kind, e) < n;
             const bool is_below = valid && b < lo_b, is_above = valid && b > hi_b;
             const bool inside = valid && !is_below && !is_above;
             acc.below += is_below;
@@ -395,21 +391,21 @@ __global__ __launch_bounds__(THREADS) void enc_bracket_kernel(EncodeJob *__restr
             int64_t x[2 * PAIRS];
             load_tile_from(values, kind, v0, n, fill, x);
             if (mode == SEL_BRACKET_HIST) {
-                if (whole) bracket_values<SEL_BRACKET_HIST, true, 0, 2 * PAIRS>(x, v0, n, lo_b, hi_b, acc, lh, nullptr, nullptr);
-                else bracket_values<SEL_BRACKET_HIST, false, 0, 2 * PAIRS>(x, v0, n, lo_b, hi_b, acc, lh, nullptr, nullptr);
+                if (whole) bracket_values<SEL_BRACKET_HIST, true, 0, 2 * PAIRS>(x, kind, v0, n, lo_b, hi_b, acc, lh, nullptr, nullptr);
+                else bracket_values<SEL_BRACKET_HIST, false, 0, 2 * PAIRS>(x, kind, v0, n, lo_b, hi_b, acc, lh, nullptr, nullptr);
             } else if (mode == SEL_FULL) {
-                bracket_values<SEL_FULL, true, 0, 2 * PAIRS>(x, v0, n, lo_b, hi_b, acc, lh, nullptr, nullptr);
+                bracket_values<SEL_FULL, true, 0, 2 * PAIRS>(x, kind, v0, n, lo_b, hi_b, acc, lh, nullptr, nullptr);
             } else if (mode == SEL_BRACKET_MICRO) {
-                if (whole) bracket_values<SEL_BRACKET_MICRO, true, 0, 2 * PAIRS>(x, v0, n, lo_b, hi_b, acc, lh, nullptr, nullptr);
-                else bracket_values<SEL_BRACKET_MICRO, false, 0, 2 * PAIRS>(x, v0, n, lo_b, hi_b, acc, lh, nullptr, nullptr);
+                if (whole) bracket_values<SEL_BRACKET_MICRO, true, 0, 2 * PAIRS>(x, kind, v0, n, lo_b, hi_b, acc, lh, nullptr, nullptr);
+                else bracket_values<SEL_BRACKET_MICRO, false, 0, 2 * PAIRS>(x, kind, v0, n, lo_b, hi_b, acc, lh, nullptr, nullptr);
             } else {
                 // a wave appends at most TILE / 2 / WAVES values per half tile
                 if (wcount + TILE / 2 / WAVES > WAVE_CAP) flush_wave();
-                if (whole) bracket_values<SEL_BRACKET_COMPACT, true, 0, PAIRS>(x, v0, n, lo_b, hi_b, acc, lh, wstage, &wcount);
-                else bracket_values<SEL_BRACKET_COMPACT, false, 0, PAIRS>(x, v0, n, lo_b, hi_b, acc, lh, wstage, &wcount);
+                if (whole) bracket_values<SEL_BRACKET_COMPACT, true, 0, PAIRS>(x, kind, v0, n, lo_b, hi_b, acc, lh, wstage, &wcount);
+                else bracket_values<SEL_BRACKET_COMPACT, false, 0, PAIRS>(x, kind, v0, n, lo_b, hi_b, acc, lh, wstage, &wcount);
                 if (wcount + TILE / 2 / WAVES > WAVE_CAP) flush_wave();
-                if (whole) bracket_values<SEL_BRACKET_COMPACT, true, PAIRS, 2 * PAIRS>(x, v0, n, lo_b, hi_b, acc, lh, wstage, &wcount);
-                else bracket_values<SEL_BRACKET_COMPACT, false, PAIRS, 2 * PAIRS>(x, v0, n, lo_b, hi_b, acc, lh, wstage, &wcount);
+                if (whole) bracket_values<SEL_BRACKET_COMPACT, true, PAIRS, 2 * PAIRS>(x, kind, v0, n, lo_b, hi_b, acc, lh, wstage, &wcount);
+                else bracket_values<SEL_BRACKET_COMPACT, false, PAIRS, 2 * PAIRS>(x, kind, v0, n, lo_b, hi_b, acc, lh, wstage, &wcount);
             }
         }
         // min / max: most waves cannot improve on what is already there: look before queueing an
@@ -582,7 +578,7 @@ __global__ __launch_bounds__(THREADS) void enc_hist_kernel(EncodeJob *__restrict
             load_tile_from(values, kind, v0, n, 0, x);
 #pragma unroll
             for (int e = 0; e < 2 * PAIRS; ++e) {
-                const uint64_t i = v0 + (e >> 1) * THREADS * 2 + threadIdx.x * 2 + (e & 1);
+                const uint64_t i = v0 + tile_slot(kind, e);
                 if (i < n) hist_key(lh, ((uint64_t)x[e] ^ SIGN) - base, pass, shift, prefix, last, above);
             }
         }
@@ -596,7 +592,7 @@ __global__ __launch_bounds__(THREADS) void enc_hist_kernel(EncodeJob *__restrict
             load_tile_from(job.cand, ZBRA_ELEM_I64, v0, end, 0, x);
 #pragma unroll
             for (int e = 0; e < 2 * PAIRS; ++e) {
-                const uint64_t i = v0 + (e >> 1) * THREADS * 2 + threadIdx.x * 2 + (e & 1);
+                const uint64_t i = v0 + tile_slot(ZBRA_ELEM_I64, e);
                 if (i < end) hist_key(lh, ((uint64_t)x[e] ^ SIGN) - base, pass, shift, prefix, last, above);
             }
         }
@@ -819,12 +815,24 @@ __device__ __forceinline__ void stage_zigzag(const EncodeJob &job, uint64_t v0, 
     const uint64_t mid = (uint64_t)job.midpoint;
     int64_t x[2 * PAIRS];
     load_tile(job, v0, v0 + nv, (int64_t)mid, x);
+    if (job.kind != ZBRA_ELEM_U32) {
 #pragma unroll
-    for (int it = 0; it < PAIRS; ++it) {
-        uint2 z;
-        z.x = (uint32_t)to_stream(job, x[2 * it], mid);
-        z.y = (uint32_t)to_stream(job, x[2 * it + 1], mid);
-        *(uint2 *)(zz + it * THREADS * 2 + tid * 2) = z;
+        for (int it = 0; it < PAIRS; ++it) {
+            uint2 z;
+            z.x = (uint32_t)to_stream(job, x[2 * it], mid);
+            z.y = (uint32_t)to_stream(job, x[2 * it + 1], mid);
+            *(uint2 *)(zz + it * THREADS * 2 + tid * 2) = z;
+        }
+    } else {
+#pragma unroll
+        for (int q = 0; q < PAIRS / 2; ++q) {
+            uint4 z;
+            z.x = (uint32_t)to_stream(job, x[4 * q], mid);
+            z.y = (uint32_t)to_stream(job, x[4 * q + 1], mid);
+            z.z = (uint32_t)to_stream(job, x[4 * q + 2], mid);
+            z.w = (uint32_t)to_stream(job, x[4 * q + 3], mid);
+            *(uint4 *)(zz + q * THREADS * 4 + tid * 4) = z;
+        }
     }
     __syncthreads();
 }
