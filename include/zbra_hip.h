@@ -175,6 +175,15 @@ int zbra_hip_bp64_unpack(const uint8_t *packed, size_t packed_len, size_t count,
 int zbra_hip_decode_dev(const uint8_t *d_data, size_t len, size_t count, void *d_out, uint32_t kind,
                         zbra_dev_result *d_result, void *stream);
 
+/* read_int_array_usize_compressed (binary.rs:661-664) fused with the running sum every consumer of
+ * a lengths array computes next (`offset += length`, striped.rs:523-583): d_offsets receives
+ * out_count + 1 words, d_offsets[0] = 0 and d_offsets[i + 1] = d_offsets[i] + lengths[i]
+ * (wrapping, as usize adds), where out_count is what decompress_int_array would return (0 for
+ * empty or rejected data: then only d_offsets[0] is written).  The lengths themselves are never
+ * stored: two reads of the packed bytes, one write of 8 bytes per value. */
+int zbra_hip_decode_offsets_dev(const uint8_t *d_data, size_t len, size_t count, uint64_t *d_offsets, zbra_dev_result *d_result,
+                                void *stream);
+
 /* The same for `nd` independent arrays in one submission (all arrays of a Block, or of many
  * Blocks: binary.rs:359-441 decodes them one after another).  `descs` is a HOST array whose
  * data/out members are DEVICE pointers; d_results (may be NULL) receives nd entries. */

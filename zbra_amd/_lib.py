@@ -64,6 +64,7 @@ SIGNATURES = {
     "zbra_hip_bp64_pack": (C.c_int, [_p, _sz, _p, _sz, _psz]),
     "zbra_hip_bp64_unpack": (C.c_int, [_p, _sz, _sz, _p, _psz]),
     "zbra_hip_decode_dev": (C.c_int, [_p, _sz, _sz, _p, C.c_uint32, _p, _p]),
+    "zbra_hip_decode_offsets_dev": (C.c_int, [_p, _sz, _sz, _p, _p, _p]),
     "zbra_hip_decode_batch_dev": (C.c_int, [C.POINTER(ArrayDesc), _sz, _p, _p]),
     "zbra_hip_encode_dev": (C.c_int, [_p, _sz, C.c_uint32, _p, _sz, _p, _p]),
     "zbra_hip_encode_batch_dev": (C.c_int, [C.POINTER(EncodeDesc), _sz, _p, _p]),

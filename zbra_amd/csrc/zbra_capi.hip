@@ -14,6 +14,7 @@
 #include "zbra_encode.hpp"
 #include "zbra_stages.hpp"
 #include "zbra_file.hpp"
+#include "zbra_offsets.hpp"
 
 namespace zbra {
 
@@ -777,6 +778,35 @@ int zbra_hip_decode_dev(const uint8_t *d_data, size_t len, size_t count, void *d
     zbra_array_desc d;
     d.data = d_data; d.len = len; d.count = count; d.out = d_out; d.kind = kind; d.reserved = 0;
     return decode_batch_dev(ctx, &d, 1, d_result, (hipStream_t)stream);
+}
+
+int zbra_hip_decode_offsets_dev(const uint8_t *d_data, size_t len, size_t count, uint64_t *d_offsets, zbra_dev_result *d_result,
+                                void *stream_) {
+    if (!d_offsets || (len && !d_data) || count > MAX_COUNT) return ZBRA_ERR_INVALID_ARG;
+    DeviceCtx *ctx;
+    ZBRA_TRY(current_ctx(&ctx));
+    hipStream_t stream = (hipStream_t)stream_;
+    const uint64_t ntiles = ((uint64_t)count + OFF_TILE - 1) / OFF_TILE;
+    const uint64_t nchunks = (ntiles + SCAN_CHUNK - 1) / SCAN_CHUNK;
+    Slot *s;
+    ZBRA_TRY(ctx->acquire(128 + (size_t)(ntiles + nchunks + 1) * sizeof(uint64_t), &s));
+    DecodePlan *plan = (DecodePlan *)s->dev;
+    uint64_t *tile_start = (uint64_t *)((char *)s->dev + 64);  // written by the plan kernel, not used here
+    uint64_t *tile_sums = (uint64_t *)((char *)s->dev + 128);
+    uint64_t *chunk_base = tile_sums + ntiles;
+    zbra_array_desc d;
+    d.data = d_data; d.len = len; d.count = count; d.out = d_offsets + 1; d.kind = ZBRA_ELEM_I64; d.reserved = 0;
+    hipLaunchKernelGGL(plan_decode_one_kernel, dim3(1), dim3(64), 0, stream, d, ntiles, plan, tile_start, d_result);
+    if (ntiles) {
+        hipLaunchKernelGGL(offsets_sums_kernel, dim3((unsigned)ntiles), dim3(OFF_THREADS), 0, stream, plan, tile_sums);
+        hipLaunchKernelGGL(offsets_scan_chunks_kernel, dim3((unsigned)nchunks), dim3(SCAN_CHUNK), 0, stream, plan, tile_sums, chunk_base);
+        hipLaunchKernelGGL(offsets_scan_totals_kernel, dim3(1), dim3(SCAN_CHUNK), 0, stream, plan, chunk_base);
+    }
+    hipLaunchKernelGGL(offsets_write_kernel, dim3((unsigned)(ntiles ? ntiles : 1)), dim3(OFF_THREADS), 0, stream, plan, tile_sums, chunk_base,
+                       d_offsets);
+    int st = hip_status(hipGetLastError());
+    int st2 = ctx->release(s, stream);
+    return st != ZBRA_OK ? st : st2;
 }
 
 int zbra_hip_decode_batch_dev(const zbra_array_desc *descs, size_t nd, zbra_dev_result *d_results, void *stream) {

@@ -1,0 +1,178 @@
+// Lengths -> offsets, fused with the decode.
+//
+// Binary, Array and Nested columns store their lengths through the int codec
+// (read_int_array_usize_compressed, zbra-core/src/binary.rs:661-664), and the first thing every
+// consumer does with them is a running sum (`offset += length`, zbra-core/src/striped.rs:523-583).
+// These kernels produce that running sum straight from the packed bytes:
+//   offsets[0] = 0, offsets[i + 1] = offsets[i] + lengths[i]          (wrapping, as usize adds)
+// in four launches: per-tile sums (decode, reduce, store nothing), a two-level exclusive scan of
+// the tile sums, and a second decode that scans inside the tile and stores the offsets.  HBM traffic is two
+// reads of the packed bytes and one write of 8 B per value; decoding the lengths first and
+// scanning them afterwards would write, read and write 8 B per value.
+#pragma once
+#include "zbra_decode.hpp"
+
+namespace zbra {
+
+constexpr int OFF_TILE = 2048;     // values per tile
+constexpr int OFF_THREADS = 512;   // lanes per workgroup
+constexpr int OFF_PER = OFF_TILE / OFF_THREADS;  // consecutive values per lane: one wave scan per tile
+constexpr int OFF_WAVES = OFF_THREADS / 64;
+static_assert(OFF_PER == 4, "a lane stores its four offsets as two 16-byte words");
+
+// Stages the packed bytes of the tile in LDS when the width is 1..31 (nothing to do otherwise).
+__device__ __forceinline__ uint32_t offsets_stage(const DecodePlan &p, uint64_t v0, uint32_t nv, uint32_t *lds) {
+    uint32_t base_bits = 0;
+    if (p.width - 1u < 31u) {
+        const PackedSpan sp = packed_span(p, v0, nv);
+        const ZBRA_GLOBAL u32x4 *src = gptr<u32x4>(sp.A0);
+        u32x4 *dst = (u32x4 *)lds;
+        for (uint32_t c = threadIdx.x; c < sp.nchunks; c += OFF_THREADS) dst[c] = ld_stream<1>(src + c);
+        base_bits = sp.base_bits;
+    }
+    __syncthreads();
+    return base_bits;
+}
+
+// Values j .. j + 3 of the tile (0 past the last one), decoded as decompress_int_array would
+// (compression.rs:295-330): un-zig-zag, add the midpoint.
+__device__ __forceinline__ void offsets_values(const DecodePlan &p, uint64_t v0, uint32_t nv, uint32_t base_bits, const uint32_t *lds,
+                                               uint32_t j, uint64_t (&v)[OFF_PER]) {
+    const uint32_t w = p.width;
+#pragma unroll
+    for (int k = 0; k < OFF_PER; k++) {
+        int64_t d;
+        if (w - 1u < 31u) {
+            d = zigzag_decode32(extract_bits(lds, base_bits + (j + k) * w, (1u << w) - 1u));
+        } else if (w == 0) {
+            d = 0;                                            // compression.rs:187-189
+        } else {                                              // raw u64, a value with missing bytes reads as 0 (:195-207)
+            const uint64_t off = (v0 + j + k) * 8;
+            d = zigzag_decode64(j + k < nv && off + 8 <= p.avail ? load_le64_bytes(p.payload + off) : 0);
+        }
+        v[k] = j + k < nv ? (uint64_t)(p.midpoint + d) : 0;
+    }
+}
+
+__device__ __forceinline__ uint64_t wave_sum_u64(uint64_t v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+// 1. tile_sums[t] = sum of the tile's values.
+__global__ __launch_bounds__(OFF_THREADS) void offsets_sums_kernel(const DecodePlan *__restrict__ plan, uint64_t *__restrict__ tile_sums) {
+    __shared__ __attribute__((aligned(16))) uint32_t lds[lds_dwords<OFF_TILE>()];
+    __shared__ uint64_t wsum[OFF_WAVES];
+    const DecodePlan p = *plan;
+    const uint64_t v0 = (uint64_t)blockIdx.x * OFF_TILE;
+    if (v0 >= p.count) return;  // rejected or empty array: uniform
+    const uint64_t left = p.count - v0;
+    const uint32_t nv = left < (uint64_t)OFF_TILE ? (uint32_t)left : (uint32_t)OFF_TILE;
+    const uint32_t base_bits = offsets_stage(p, v0, nv, lds);
+    uint64_t v[OFF_PER];
+    offsets_values(p, v0, nv, base_bits, lds, threadIdx.x * OFF_PER, v);
+    uint64_t sum = (v[0] + v[1]) + (v[2] + v[3]);
+    sum = wave_sum_u64(sum);
+    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = sum;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint64_t t = 0;
+#pragma unroll
+        for (int k = 0; k < OFF_WAVES; k++) t += wsum[k];
+        tile_sums[blockIdx.x] = t;
+    }
+}
+
+// 2. Exclusive scan of the tile sums in two levels: every workgroup scans one chunk of SCAN_CHUNK
+// consecutive sums in place (coalesced: lane t holds sum t of the chunk) and leaves the chunk's
+// total in chunk_base[c]; one workgroup then turns the totals into exclusive prefixes.  A
+// 2^32-value array has 2^21 tiles = 2048 chunks, which the second level takes two per lane.
+constexpr int SCAN_CHUNK = 1024;
+__device__ __forceinline__ uint64_t block_exclusive_scan_1024(uint64_t x, uint64_t *wtot, uint64_t *total) {
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    uint64_t inc = x;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint64_t up = __shfl_up(inc, o);
+        if (lane >= (uint32_t)o) inc += up;
+    }
+    if (lane == 63) wtot[wave] = inc;
+    __syncthreads();
+    uint64_t before = 0, all = 0;
+    for (uint32_t k = 0; k < SCAN_CHUNK / 64; k++) { if (k < wave) before += wtot[k]; all += wtot[k]; }
+    __syncthreads();
+    *total = all;
+    return before + inc - x;
+}
+__global__ __launch_bounds__(SCAN_CHUNK) void offsets_scan_chunks_kernel(const DecodePlan *__restrict__ plan, uint64_t *__restrict__ tile_sums,
+                                                                          uint64_t *__restrict__ chunk_base) {
+    __shared__ uint64_t wtot[SCAN_CHUNK / 64];
+    const uint64_t ntiles = (plan->count + OFF_TILE - 1) / OFF_TILE;
+    const uint64_t t = (uint64_t)blockIdx.x * SCAN_CHUNK + threadIdx.x;
+    if ((uint64_t)blockIdx.x * SCAN_CHUNK >= ntiles) return;  // uniform
+    const uint64_t x = t < ntiles ? tile_sums[t] : 0;
+    uint64_t total;
+    const uint64_t ex = block_exclusive_scan_1024(x, wtot, &total);
+    if (t < ntiles) tile_sums[t] = ex;
+    if (threadIdx.x == 0) chunk_base[blockIdx.x] = total;
+}
+__global__ __launch_bounds__(SCAN_CHUNK) void offsets_scan_totals_kernel(const DecodePlan *__restrict__ plan, uint64_t *__restrict__ chunk_base) {
+    __shared__ uint64_t wtot[SCAN_CHUNK / 64];
+    const uint64_t ntiles = (plan->count + OFF_TILE - 1) / OFF_TILE;
+    const uint64_t nchunks = (ntiles + SCAN_CHUNK - 1) / SCAN_CHUNK;
+    uint64_t carry = 0;
+    for (uint64_t c0 = 0; c0 < nchunks; c0 += SCAN_CHUNK) {  // uniform trip count
+        const uint64_t c = c0 + threadIdx.x;
+        const uint64_t x = c < nchunks ? chunk_base[c] : 0;
+        uint64_t total;
+        const uint64_t ex = block_exclusive_scan_1024(x, wtot, &total);
+        if (c < nchunks) chunk_base[c] = carry + ex;
+        carry += total;
+    }
+}
+
+// 3. offsets[v0 + j + 1] = (sum of all earlier tiles) + (inclusive sum of the tile's values 0..j);
+// offsets[0] = 0.  `chunk_base[c]` is the sum of the tiles before chunk c of SCAN_CHUNK tiles and
+// `tile_sums[t]` the sum of the earlier tiles of t's own chunk.
+__global__ __launch_bounds__(OFF_THREADS) void offsets_write_kernel(const DecodePlan *__restrict__ plan, const uint64_t *__restrict__ tile_sums,
+                                                                     const uint64_t *__restrict__ chunk_base, uint64_t *__restrict__ offsets) {
+    __shared__ __attribute__((aligned(16))) uint32_t lds[lds_dwords<OFF_TILE>()];
+    __shared__ uint64_t wtot[OFF_WAVES];
+    const DecodePlan p = *plan;
+    if (blockIdx.x == 0 && threadIdx.x == 0) offsets[0] = 0;
+    const uint64_t v0 = (uint64_t)blockIdx.x * OFF_TILE;
+    if (v0 >= p.count) return;  // uniform
+    const uint64_t left = p.count - v0;
+    const uint32_t nv = left < (uint64_t)OFF_TILE ? (uint32_t)left : (uint32_t)OFF_TILE;
+    const uint32_t base_bits = offsets_stage(p, v0, nv, lds);
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6, j = threadIdx.x * OFF_PER;
+    uint64_t v[OFF_PER];
+    offsets_values(p, v0, nv, base_bits, lds, j, v);
+    const uint64_t mine = (v[0] + v[1]) + (v[2] + v[3]);
+    uint64_t inc = mine;  // inclusive scan of the lanes' totals across the wave
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint64_t up = __shfl_up(inc, o);
+        if (lane >= (uint32_t)o) inc += up;
+    }
+    if (lane == 63) wtot[wave] = inc;
+    __syncthreads();
+    uint64_t run = chunk_base[blockIdx.x / SCAN_CHUNK] + tile_sums[blockIdx.x] + inc - mine;
+    for (uint32_t k = 0; k < wave; k++) run += wtot[k];
+    uint64_t o[OFF_PER];
+#pragma unroll
+    for (int k = 0; k < OFF_PER; k++) { run += v[k]; o[k] = run; }
+    ZBRA_GLOBAL uint64_t *out = gptr_mut<uint64_t>(offsets) + v0 + 1 + j;
+    if (j + OFF_PER <= nv) {  // 32 contiguous bytes per lane, 2 KiB per wave
+        const u64x2 lo = {o[0], o[1]}, hi = {o[2], o[3]};
+        __builtin_nontemporal_store(lo, (ZBRA_GLOBAL u64x2 *)out);
+        __builtin_nontemporal_store(hi, (ZBRA_GLOBAL u64x2 *)(out + 2));
+    } else {
+#pragma unroll
+        for (int k = 0; k < OFF_PER; k++)
+            if (j + k < nv) out[k] = o[k];
+    }
+}
+
+}  // namespace zbra

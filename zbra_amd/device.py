@@ -58,6 +58,19 @@ def decode_dev(encoded: torch.Tensor, count: int, out: torch.Tensor, result: tor
         _raise(st)
 
 
+def decode_offsets_dev(encoded: torch.Tensor, count: int, offsets: torch.Tensor, result: torch.Tensor = None, length: int = None,
+                       stream=None):
+    """zbra_hip_decode_offsets_dev: a lengths array (binary.rs:661-664) decoded straight into its
+    running sum; `offsets` is an int64/uint64 CUDA tensor of count + 1 words."""
+    assert encoded.is_cuda and encoded.dtype == torch.uint8 and offsets.is_cuda and offsets.element_size() == 8
+    assert offsets.numel() >= count + 1
+    n = encoded.numel() if length is None else length
+    st = lib.zbra_hip_decode_offsets_dev(encoded.data_ptr(), n, count, offsets.data_ptr(),
+                                         result.data_ptr() if result is not None else None, _stream_handle(stream))
+    if st:
+        _raise(st)
+
+
 def make_descs(items):
     """items: iterable of (data_ptr, len, count, out_ptr, kind) -> ctypes array of zbra_array_desc."""
     items = list(items)
