@@ -22,14 +22,28 @@
 
 namespace zbra {
 
+// A stretch of a device range and where it is (or goes) in host memory.
+struct PipeSegment {
+    size_t dev_off;
+    void *host;
+    size_t len;
+};
+
 // Process-wide memcpy workers.  Never destroyed: the threads sleep on the condition variable and
 // die with the process, so no static destructor can race them.
 class CopyWorkers {
    public:
+    // One piece of a transfer: the part [lo, hi) of a device range, whose image in the ring
+    // starts at `img` for offset `img_off`, against the host segments segs[s0 ..] that overlap it
+    // (a large array is one long segment, a Block of small arrays thousands of short ones: either
+    // way a piece is about PIECE bytes of memcpy, never one queue entry per tiny array).
     struct Task {
-        void *dst;
-        const void *src;
-        size_t len;
+        const PipeSegment *segs;
+        size_t s0, nsegs;
+        size_t lo, hi;
+        char *img;
+        size_t img_off;
+        bool to_host;
         std::atomic<int> *pending;  // decremented when the piece has been copied
     };
 
@@ -81,7 +95,15 @@ class CopyWorkers {
     }
 
     static void run(const Task &t) {
-        std::memcpy(t.dst, t.src, t.len);
+        for (size_t j = t.s0; j < t.nsegs && t.segs[j].dev_off < t.hi; j++) {
+            const PipeSegment &g = t.segs[j];
+            const size_t lo = g.dev_off > t.lo ? g.dev_off : t.lo;
+            const size_t end = g.dev_off + g.len, hi = end < t.hi ? end : t.hi;
+            if (hi <= lo) continue;
+            char *h = (char *)g.host + (lo - g.dev_off), *r = t.img + (lo - t.img_off);
+            if (t.to_host) std::memcpy(h, r, hi - lo);
+            else std::memcpy(r, h, hi - lo);
+        }
         t.pending->fetch_sub(1, std::memory_order_release);
     }
 
@@ -124,6 +146,7 @@ struct HostPipe {
         return v >= 2 && v <= (long)MAX_SLOTS ? (size_t)v : (size_t)8;
     }();
     static constexpr size_t MIN_BYTES = (size_t)1 << 20;  // below this a plain hipMemcpyAsync is as good
+    static constexpr size_t DIRECT_SEGS = 4;              // ... if it is not cut into many pieces
 
     char *ring = nullptr;
     size_t slot_bytes = 0;               // size of one ring slot
@@ -195,19 +218,16 @@ struct HostPipe {
         for (size_t i = 0; i < SLOTS; i++) CopyWorkers::instance().wait_zero(pending[i]);
     }
 
-    // A stretch of the device range and where it goes in host memory.
-    struct Segment {
-        size_t dev_off;
-        void *host;
-        size_t len;
-    };
+    using Segment = PipeSegment;
 
     // host -> device: the device range [dev, dev + bytes) is filled from the segments (sorted by
     // dev_off, not overlapping; gaps are left as they are on the device side of the chunk, i.e.
     // they receive whatever the ring held).  Returns when the host memory has been read
     // completely; the device copies are ordered on `stream` like a hipMemcpyAsync.
     int to_device_segments(const Segment *segs, size_t nsegs, void *dev, size_t bytes, hipStream_t stream) {
-        if (bytes < MIN_BYTES || !enabled()) {
+        // a few short segments: one plain copy each; many short segments are gathered in the ring
+        // and go up in one DMA (a copy call costs microseconds, thousands of them milliseconds)
+        if ((bytes < MIN_BYTES && nsegs <= DIRECT_SEGS) || !enabled()) {
             for (size_t j = 0; j < nsegs; j++)
                 if (segs[j].len)
                     ZBRA_HIP_TRY(hipMemcpyAsync((char *)dev + segs[j].dev_off, segs[j].host, segs[j].len, hipMemcpyHostToDevice, stream));
@@ -249,26 +269,19 @@ struct HostPipe {
     // Queues the memcpys between the ring image `img` of the part [off, off + len) of the device
     // range and the segments that part overlaps: TO_HOST true = image -> segments, false =
     // segments -> image.  `si` is the first segment that can still overlap (segments are sorted by
-    // dev_off and do not overlap; gaps are padding).
+    // dev_off and do not overlap; gaps are padding).  One task per PIECE bytes of the range.
     template <bool TO_HOST>
     void deliver(size_t slot, char *img, size_t off, size_t len, const Segment *segs, size_t nsegs, size_t &si) {
         CopyWorkers &w = CopyWorkers::instance();
         while (si < nsegs && segs[si].dev_off + segs[si].len <= off) si++;
-        int pieces = 0;
-        for (int pass = 0; pass < 2; pass++) {
-            if (pass == 1) {
-                if (pieces == 0) return;
-                pending[slot].store(pieces, std::memory_order_relaxed);
-            }
-            for (size_t j = si; j < nsegs && segs[j].dev_off < off + len; j++) {
-                const size_t lo = segs[j].dev_off > off ? segs[j].dev_off : off;
-                const size_t end = segs[j].dev_off + segs[j].len, hi = end < off + len ? end : off + len;
-                for (size_t o = lo; o < hi; o += PIECE) {
-                    if (pass == 0) { pieces++; continue; }
-                    char *h = (char *)segs[j].host + (o - segs[j].dev_off), *r = img + (o - off);
-                    w.submit({TO_HOST ? h : r, TO_HOST ? r : h, hi - o < PIECE ? hi - o : PIECE, &pending[slot]});
-                }
-            }
+        if (si >= nsegs || segs[si].dev_off >= off + len) return;  // only padding in this part
+        const int pieces = (int)((len + PIECE - 1) / PIECE);
+        pending[slot].store(pieces, std::memory_order_relaxed);
+        size_t s0 = si;
+        for (size_t lo = off; lo < off + len; lo += PIECE) {
+            const size_t hi = lo + PIECE < off + len ? lo + PIECE : off + len;
+            while (s0 < nsegs && segs[s0].dev_off + segs[s0].len <= lo) s0++;
+            w.submit({segs, s0, nsegs, lo, hi, img, off, TO_HOST, &pending[slot]});
         }
     }
 
@@ -279,7 +292,7 @@ struct HostPipe {
     // that produces those bytes, so that producing and copying back overlap.
     template <typename Before>
     int to_host_segments(const Segment *segs, size_t nsegs, const void *dev, size_t bytes, hipStream_t stream, Before &&before) {
-        if (bytes < MIN_BYTES || !enabled()) {
+        if ((bytes < MIN_BYTES && nsegs <= DIRECT_SEGS) || !enabled()) {
             ZBRA_TRY(before(bytes));
             for (size_t j = 0; j < nsegs; j++)
                 if (segs[j].len)
