@@ -217,9 +217,11 @@ __device__ __forceinline__ void set_midpoint(EncodeJob &j, int64_t a, int64_t b,
 // A wave owns 64 consecutive pairs, so in a stage with stride <= 64 it touches exactly the 128
 // elements [128 * (p0 / 64), +128) and no other wave does: runs of such stages need no workgroup
 // barrier, only the wave's own LDS ordering (20 barriers instead of 78 for 4096 keys).
-__device__ __forceinline__ void sort_keys_lds(uint64_t *sk) {
+// Sorts the first m keys (m a power of two, 2 <= m <= SAMPLE): a short array only pays for its
+// own length, not for the full sample.
+__device__ __forceinline__ void sort_keys_lds(uint64_t *sk, uint32_t m) {
     uint32_t prev_stride = 128;  // the keys were written by other waves
-    for (uint32_t size = 2; size <= (uint32_t)SAMPLE; size <<= 1) {
+    for (uint32_t size = 2; size <= m; size <<= 1) {
         for (uint32_t stride = size >> 1; stride > 0; stride >>= 1) {
             if (stride > 64 || prev_stride > 64) {
                 __syncthreads();
@@ -229,7 +231,7 @@ __device__ __forceinline__ void sort_keys_lds(uint64_t *sk) {
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
             }
             prev_stride = stride;
-            for (uint32_t t = threadIdx.x; t < (uint32_t)SAMPLE / 2; t += SAMPLE_THREADS) {
+            for (uint32_t t = threadIdx.x; t < m / 2; t += SAMPLE_THREADS) {
                 const uint32_t lo = 2 * t - (t & (stride - 1));  // index of the lower partner
                 const uint32_t hi = lo + stride;
                 const bool up = (lo & size) == 0;
@@ -252,7 +254,9 @@ __global__ __launch_bounds__(SAMPLE_THREADS) void enc_sample_kernel(EncodeJob *_
 
     const bool whole = n <= (uint64_t)SAMPLE;
     const uint64_t stride = whole ? 1 : n / SAMPLE;
-    for (uint32_t j = threadIdx.x; j < (uint32_t)SAMPLE; j += SAMPLE_THREADS) {
+    uint32_t m = (uint32_t)SAMPLE;  // keys to sort: the next power of two >= n for a short array
+    if (whole) { m = 2; while (m < (uint32_t)n) m <<= 1; }
+    for (uint32_t j = threadIdx.x; j < m; j += SAMPLE_THREADS) {
         uint64_t key = ~0ull;  // padding of a short array sorts to the end
         if (whole) {
             if (j < n) key = (uint64_t)load_value(job, j) ^ SIGN;
@@ -265,7 +269,7 @@ __global__ __launch_bounds__(SAMPLE_THREADS) void enc_sample_kernel(EncodeJob *_
         }
         sk[j] = key;
     }
-    sort_keys_lds(sk);
+    sort_keys_lds(sk, m);
     if (threadIdx.x != 0) return;
     const uint64_t k = (n - 1) / 2;  // rank of a: n/2 - 1 for even n, n/2 for odd n
     if (whole) {
