@@ -177,7 +177,7 @@ static int decode_batch_dev(DeviceCtx *ctx, const zbra_array_desc *descs, size_t
     for (size_t i = 0; i < nd; i++) ntiles += decode_tiles_of(descs[i].count, descs[i].kind);
     const size_t total = off_map + ntiles * sizeof(uint32_t);  // the map lives on the device only
     Slot *s;
-    ZBRA_TRY(ctx->acquire(total, &s));
+    ZBRA_TRY(ctx->acquire(total, &s, 0, off_ts + (nd + 1) * sizeof(uint64_t)));  // plans and the map live on the device only
     std::memcpy(s->host, descs, nd * sizeof(zbra_array_desc));
     uint64_t *h_ts = (uint64_t *)((char *)s->host + off_ts);
     uint64_t run = 0;
@@ -242,7 +242,7 @@ static int encode_batch_dev(DeviceCtx *ctx, const EncodeItem *items, size_t nd, 
     size_t scratch_bytes = 0;
     for (size_t i = 0; i < nd; i++) scratch_bytes += seg_cap_of(items[i]) * CAND_SEGS * sizeof(int64_t);
     Slot *s;
-    ZBRA_TRY(ctx->acquire(total, &s, scratch_bytes));
+    ZBRA_TRY(ctx->acquire(total, &s, scratch_bytes, off_list + nd * sizeof(uint32_t)));  // histograms and counters: device only
     EncodeJob *h_jobs = (EncodeJob *)s->host;
     uint64_t *h_ts = (uint64_t *)((char *)s->host + off_ts);
     uint32_t *h_list = (uint32_t *)((char *)s->host + off_list);
@@ -789,7 +789,7 @@ int zbra_hip_decode_offsets_dev(const uint8_t *d_data, size_t len, size_t count,
     const uint64_t ntiles = ((uint64_t)count + OFF_TILE - 1) / OFF_TILE;
     const uint64_t nchunks = (ntiles + SCAN_CHUNK - 1) / SCAN_CHUNK;
     Slot *s;
-    ZBRA_TRY(ctx->acquire(128 + (size_t)(ntiles + nchunks + 1) * sizeof(uint64_t), &s));
+    ZBRA_TRY(ctx->acquire(128 + (size_t)(ntiles + nchunks + 1) * sizeof(uint64_t), &s, 0, 64));  // nothing comes from the host
     DecodePlan *plan = (DecodePlan *)s->dev;
     uint64_t *tile_start = (uint64_t *)((char *)s->dev + 64);  // written by the plan kernel, not used here
     uint64_t *tile_sums = (uint64_t *)((char *)s->dev + 128);

@@ -30,13 +30,14 @@ inline int hip_status(hipError_t e) { return e == hipSuccess ? ZBRA_OK : ZBRA_ER
 
 namespace zbra {
 
-// A pair of equally sized buffers (pinned host + device) lent to ONE enqueued call.  The host
+// A pair of buffers (device + its pinned host twin for the part the host fills) lent to ONE enqueued call.  The host
 // side may be rewritten only after everything the previous borrower enqueued has run, which the
 // slot's event says.
 struct Slot {
     void *host = nullptr;
     void *dev = nullptr;
-    size_t cap = 0;
+    size_t cap = 0;       // of dev
+    size_t host_cap = 0;  // of host
     void *scratch = nullptr;  // device-only memory of the borrower (candidate lists of an encode)
     size_t scratch_cap = 0;
     hipEvent_t done = nullptr;
@@ -75,11 +76,14 @@ struct DeviceCtx {
     HostPipe pipe;              // pageable host memory <-> device, under host_mu
     HostPipe pipe_up;           // uploads issued while `pipe` is busy with the way back (piecewise decode)
 
-    // scratch_bytes of device-only memory come with the slot (grown while the slot is idle).
-    int acquire(size_t bytes, Slot **out, size_t scratch_bytes = 0) {
+    // A slot whose device buffer holds `bytes` and whose pinned host buffer holds `host_bytes`
+    // (0 = as large as the device buffer: only the part the host fills needs a pinned twin);
+    // scratch_bytes of further device-only memory come with it (grown while the slot is idle).
+    int acquire(size_t bytes, Slot **out, size_t scratch_bytes = 0, size_t host_bytes = 0) {
+        if (host_bytes == 0 || host_bytes > bytes) host_bytes = bytes;
         std::lock_guard<std::mutex> g(mu);
         for (Slot *s : slots) {
-            if (s->busy || s->cap < bytes) continue;
+            if (s->busy || s->cap < bytes || s->host_cap < host_bytes) continue;
             if (hipEventQuery(s->done) != hipSuccess) {
                 (void)hipGetLastError();  // hipErrorNotReady is not a failure
                 continue;
@@ -95,8 +99,8 @@ struct DeviceCtx {
             return ZBRA_OK;
         }
         Slot *s = new Slot();
-        size_t cap = bytes < 4096 ? 4096 : bytes;
-        hipError_t e = hipHostMalloc(&s->host, cap, hipHostMallocDefault);
+        const size_t cap = bytes < 4096 ? 4096 : bytes, hcap = host_bytes < 4096 ? 4096 : host_bytes;
+        hipError_t e = hipHostMalloc(&s->host, hcap, hipHostMallocDefault);
         if (e == hipSuccess) e = hipMalloc(&s->dev, cap);
         if (e == hipSuccess && scratch_bytes) {
             e = hipMalloc(&s->scratch, scratch_bytes);
@@ -111,6 +115,7 @@ struct DeviceCtx {
             return hip_status(e);
         }
         s->cap = cap;
+        s->host_cap = hcap;
         s->busy = true;
         slots.push_back(s);
         *out = s;
