@@ -60,28 +60,54 @@ __device__ __forceinline__ uint64_t wave_sum_u64(uint64_t v) {
     return v;
 }
 
-// 1. tile_sums[t] = sum of the tile's values.
+// 1. tile_sums[t] = sum of the tile's values.  A workgroup's life is one memory latency (load the
+// packed bytes, then reduce), so it takes OFF_SUM_TILES consecutive tiles at once: all their loads
+// are in flight together and the latency is paid once per OFF_SUM_TILES tiles.
+constexpr int OFF_SUM_TILES = 4;
 __global__ __launch_bounds__(OFF_THREADS) void offsets_sums_kernel(const DecodePlan *__restrict__ plan, uint64_t *__restrict__ tile_sums) {
-    __shared__ __attribute__((aligned(16))) uint32_t lds[lds_dwords<OFF_TILE>()];
-    __shared__ uint64_t wsum[OFF_WAVES];
+    __shared__ __attribute__((aligned(16))) uint32_t lds[OFF_SUM_TILES][lds_dwords<OFF_TILE>()];
+    __shared__ uint64_t wsum[OFF_SUM_TILES][OFF_WAVES];
     const DecodePlan p = *plan;
-    const uint64_t v0 = (uint64_t)blockIdx.x * OFF_TILE;
-    if (v0 >= p.count) return;  // rejected or empty array: uniform
-    const uint64_t left = p.count - v0;
-    const uint32_t nv = left < (uint64_t)OFF_TILE ? (uint32_t)left : (uint32_t)OFF_TILE;
-    const uint32_t base_bits = offsets_stage(p, v0, nv, lds);
-    uint64_t v[OFF_PER];
-    offsets_values(p, v0, nv, base_bits, lds, threadIdx.x * OFF_PER, v);
-    uint64_t sum = (v[0] + v[1]) + (v[2] + v[3]);
-    sum = wave_sum_u64(sum);
-    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = sum;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        uint64_t t = 0;
+    const uint64_t t0 = (uint64_t)blockIdx.x * OFF_SUM_TILES;
+    if (t0 * OFF_TILE >= p.count) return;  // rejected or empty array: uniform
+    uint32_t nv[OFF_SUM_TILES], base_bits[OFF_SUM_TILES];
 #pragma unroll
-        for (int k = 0; k < OFF_WAVES; k++) t += wsum[k];
-        tile_sums[blockIdx.x] = t;
+    for (int q = 0; q < OFF_SUM_TILES; q++) {
+        const uint64_t v0 = (t0 + q) * OFF_TILE;
+        nv[q] = 0; base_bits[q] = 0;
+        if (v0 < p.count) {
+            const uint64_t left = p.count - v0;
+            nv[q] = left < (uint64_t)OFF_TILE ? (uint32_t)left : (uint32_t)OFF_TILE;
+            if (p.width - 1u < 31u) {
+                const PackedSpan sp = packed_span(p, v0, nv[q]);
+                const ZBRA_GLOBAL u32x4 *src = gptr<u32x4>(sp.A0);
+                u32x4 *dst = (u32x4 *)lds[q];
+                for (uint32_t c = threadIdx.x; c < sp.nchunks; c += OFF_THREADS) dst[c] = ld_stream<1>(src + c);
+                base_bits[q] = sp.base_bits;
+            }
+        }
     }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < OFF_SUM_TILES; q++) {
+        uint64_t sum = 0;
+        if (nv[q]) {
+            uint64_t v[OFF_PER];
+            offsets_values(p, (t0 + q) * OFF_TILE, nv[q], base_bits[q], lds[q], threadIdx.x * OFF_PER, v);
+            sum = (v[0] + v[1]) + (v[2] + v[3]);
+        }
+        sum = wave_sum_u64(sum);
+        if ((threadIdx.x & 63) == 0) wsum[q][threadIdx.x >> 6] = sum;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < OFF_SUM_TILES; q++)
+        if (threadIdx.x == (uint32_t)q && nv[q]) {
+            uint64_t t = 0;
+#pragma unroll
+            for (int k = 0; k < OFF_WAVES; k++) t += wsum[q][k];
+            tile_sums[t0 + q] = t;
+        }
 }
 
 // 2. Exclusive scan of the tile sums in two levels: every workgroup scans one chunk of SCAN_CHUNK
