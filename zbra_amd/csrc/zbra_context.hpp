@@ -82,12 +82,14 @@ struct DeviceCtx {
     int acquire(size_t bytes, Slot **out, size_t scratch_bytes = 0, size_t host_bytes = 0) {
         if (host_bytes == 0 || host_bytes > bytes) host_bytes = bytes;
         std::lock_guard<std::mutex> g(mu);
+        Slot *small = nullptr;  // an idle slot that is too small: regrown rather than left behind
         for (Slot *s : slots) {
-            if (s->busy || s->cap < bytes || s->host_cap < host_bytes) continue;
+            if (s->busy) continue;
             if (hipEventQuery(s->done) != hipSuccess) {
                 (void)hipGetLastError();  // hipErrorNotReady is not a failure
                 continue;
             }
+            if (s->cap < bytes || s->host_cap < host_bytes) { small = s; continue; }
             if (s->scratch_cap < scratch_bytes) {
                 if (s->scratch) ZBRA_HIP_TRY(hipFree(s->scratch));
                 s->scratch = nullptr; s->scratch_cap = 0;
@@ -98,26 +100,33 @@ struct DeviceCtx {
             *out = s;
             return ZBRA_OK;
         }
-        Slot *s = new Slot();
         const size_t cap = bytes < 4096 ? 4096 : bytes, hcap = host_bytes < 4096 ? 4096 : host_bytes;
-        hipError_t e = hipHostMalloc(&s->host, hcap, hipHostMallocDefault);
-        if (e == hipSuccess) e = hipMalloc(&s->dev, cap);
-        if (e == hipSuccess && scratch_bytes) {
+        const bool fresh = small == nullptr;
+        Slot *s = fresh ? new Slot() : small;
+        hipError_t e = hipSuccess;
+        if (!fresh) {  // everything enqueued with it has run (its event says so)
+            if (s->cap < cap) { (void)hipFree(s->dev); s->dev = nullptr; s->cap = 0; }
+            if (s->host_cap < hcap) { (void)hipHostFree(s->host); s->host = nullptr; s->host_cap = 0; }
+            if (s->scratch_cap < scratch_bytes && s->scratch) { (void)hipFree(s->scratch); s->scratch = nullptr; s->scratch_cap = 0; }
+        }
+        if (!s->host) { e = hipHostMalloc(&s->host, hcap, hipHostMallocDefault); if (e == hipSuccess) s->host_cap = hcap; }
+        if (e == hipSuccess && !s->dev) { e = hipMalloc(&s->dev, cap); if (e == hipSuccess) s->cap = cap; }
+        if (e == hipSuccess && scratch_bytes && !s->scratch) {
             e = hipMalloc(&s->scratch, scratch_bytes);
             if (e == hipSuccess) s->scratch_cap = scratch_bytes;
         }
-        if (e == hipSuccess) e = hipEventCreateWithFlags(&s->done, hipEventDisableTiming);
+        if (e == hipSuccess && !s->done) e = hipEventCreateWithFlags(&s->done, hipEventDisableTiming);
         if (e != hipSuccess) {
-            if (s->host) (void)hipHostFree(s->host);
-            if (s->dev) (void)hipFree(s->dev);
-            if (s->scratch) (void)hipFree(s->scratch);
-            delete s;
+            if (fresh) {
+                if (s->host) (void)hipHostFree(s->host);
+                if (s->dev) (void)hipFree(s->dev);
+                if (s->scratch) (void)hipFree(s->scratch);
+                delete s;
+            }  // a regrown slot stays in the list with whatever buffers it still has (caps say which)
             return hip_status(e);
         }
-        s->cap = cap;
-        s->host_cap = hcap;
         s->busy = true;
-        slots.push_back(s);
+        if (fresh) slots.push_back(s);
         *out = s;
         return ZBRA_OK;
     }
