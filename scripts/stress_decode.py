@@ -1,0 +1,89 @@
+#!/usr/bin/env python3
+"""Randomised decode batches against the CPU oracle: payloads are random BYTES under crafted
+headers (any width byte 0..255, any midpoint, counts up to 2^22, short raw tails, trailing bytes
+the decoder must ignore, truncated packed payloads that must be rejected), decoded to int64 and to
+u32, device-resident and batched.  Usage: stress_decode.py [--trials N] [--seed S]"""
+import argparse
+import os
+import struct
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np
+
+
+def craft(rng, max_log2):
+    lg = int(rng.integers(0, max_log2 + 1))
+    count = int(rng.integers(1, (1 << lg) + 1))
+    pick = rng.integers(0, 10)
+    w = int(rng.integers(0, 32)) if pick < 6 else int(rng.integers(32, 72)) if pick < 9 else int(rng.integers(72, 256))
+    mid = int(rng.integers(-(1 << 63), 1 << 63, dtype=np.int64)) if rng.integers(0, 2) else int(rng.integers(-1000, 1000))
+    need = 0 if w == 0 else (count * w + 7) // 8 if w < 32 else 8 * count
+    kind = rng.integers(0, 6)
+    have = need
+    if kind == 0 and need:
+        have = int(rng.integers(0, need))          # short: rejected when packed, zero-filled when raw
+    payload = rng.integers(0, 256, have, dtype=np.uint8).tobytes()
+    e = struct.pack("<qIB", mid, 1 + have, w) + payload
+    if kind == 1:
+        e += rng.integers(0, 256, int(rng.integers(1, 40)), dtype=np.uint8).tobytes()  # trailing bytes are ignored
+    return e, count
+
+
+def run_trial(torch, device, L, oc, seed, max_log2=22, max_arrays=60):
+    rng = np.random.default_rng(seed)
+    na = int(rng.integers(1, max_arrays + 1))
+    items = [craft(rng, max_log2) for _ in range(na)]
+    budget = 1 << 26
+    kept = []
+    for e, c in items:
+        if c <= budget:
+            kept.append((e, c)); budget -= c
+    items = kept
+    kinds = [L.ELEM_U32 if rng.integers(0, 3) == 0 else L.ELEM_I64 for _ in items]
+    blob = bytearray()
+    offs = []
+    for e, _ in items:
+        blob += bytes(int(rng.integers(0, 7)))       # arbitrary byte alignment, as in a file image
+        offs.append(len(blob))
+        blob += e
+    d_blob = torch.frombuffer(bytearray(blob) + bytearray(64), dtype=torch.uint8).cuda()
+    outs = [torch.full((c + 2,), 0x5A5A5A5A, dtype=torch.int64 if k == L.ELEM_I64 else torch.int32, device="cuda") for (_, c), k in zip(items, kinds)]
+    descs = device.make_descs([(d_blob.data_ptr() + o, len(e), c, out.data_ptr() + out.element_size(), k)
+                               for (e, c), o, out, k in zip(items, offs, outs, kinds)])
+    res = device.new_results(len(items), "cuda")
+    device.decode_batch_dev(descs, res)
+    rs = device.read_results(res)
+    for i, ((e, c), k, out, r) in enumerate(zip(items, kinds, outs, rs)):
+        st, want = oc.decompress_int_array(e, c)
+        assert r.status == st, (seed, i, r.status, st, e[12], c)
+        got = out.cpu().numpy()
+        guard = got.dtype.type(0x5A5A5A5A)
+        assert got[0] == guard and got[-1] == guard, (seed, i, "guard")
+        if st == 0:
+            assert r.out_count == want.size == c
+            exp = want if k == L.ELEM_I64 else want.astype(np.uint32).view(np.int32)
+            assert np.array_equal(got[1:-1], exp), (seed, i, e[12], c, k)
+        else:
+            assert r.out_count == 0 and (got == guard).all(), (seed, i, "rejected array was written")
+    return len(items)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--trials", type=int, default=40)
+    ap.add_argument("--seed", type=int, default=1)
+    args = ap.parse_args()
+    import torch
+
+    from oracle import zbra_oracle_c as oc
+    from zbra_amd import _lib, device
+    total = 0
+    for t in range(args.trials):
+        total += run_trial(torch, device, _lib, oc, args.seed + t)
+    print(f"{args.trials} trials, {total} arrays: every status and every decoded value equals the oracle's")
+
+
+if __name__ == "__main__":
+    main()

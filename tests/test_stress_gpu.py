@@ -18,3 +18,15 @@ def test_random_batches(seed, max_log2, max_arrays):
     import stress_encode
     from zbra_amd import _lib, device
     assert stress_encode.run_trial(torch, device, _lib, seed, max_log2, max_arrays) > 0
+
+
+@pytest.mark.parametrize("seed", [11, 12, 13, 14])
+def test_random_decode_batches(seed):
+    """Random payload bytes under crafted headers (any width byte, short tails, trailing bytes):
+    statuses and values against the oracle, guard words around every output."""
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need a device"
+    import stress_decode
+    from oracle import zbra_oracle_c as oc
+    from zbra_amd import _lib, device
+    assert stress_decode.run_trial(torch, device, _lib, oc, seed) > 0
