@@ -158,15 +158,23 @@ __global__ __launch_bounds__(SCAN_CHUNK) void offsets_scan_totals_kernel(const D
     }
 }
 
-// 3. offsets[v0 + j + 1] = (sum of all earlier tiles) + (inclusive sum of the tile's values 0..j);
-// offsets[0] = 0.  `chunk_base[c]` is the sum of the tiles before chunk c of SCAN_CHUNK tiles and
-// `tile_sums[t]` the sum of the earlier tiles of t's own chunk.
+// 3. offsets[v0 + j] = (sum of all earlier tiles) + (sum of the tile's values before j), i.e. the
+// EXCLUSIVE prefix of value j goes to index v0 + j: a lane's four offsets then start at a multiple
+// of four and its two 16-byte stores are aligned whenever `offsets` is (writing the inclusive
+// prefixes to v0 + j + 1 instead straddles every 16-byte word and cost a third more time).
+// offsets[0] = 0 falls out; offsets[count] is written by the lane that holds the last value.
+// `chunk_base[c]` is the sum of the tiles before chunk c of SCAN_CHUNK tiles and `tile_sums[t]` the
+// sum of the earlier tiles of t's own chunk.
 __global__ __launch_bounds__(OFF_THREADS) void offsets_write_kernel(const DecodePlan *__restrict__ plan, const uint64_t *__restrict__ tile_sums,
                                                                      const uint64_t *__restrict__ chunk_base, uint64_t *__restrict__ offsets) {
     __shared__ __attribute__((aligned(16))) uint32_t lds[lds_dwords<OFF_TILE>()];
+    __shared__ __attribute__((aligned(16))) u64x2 turn[OFF_WAVES][64 * OFF_PER / 2];  // a wave's 256 offsets
     __shared__ uint64_t wtot[OFF_WAVES];
     const DecodePlan p = *plan;
-    if (blockIdx.x == 0 && threadIdx.x == 0) offsets[0] = 0;
+    if (p.count == 0) {  // empty or rejected: the running sum of nothing
+        if (blockIdx.x == 0 && threadIdx.x == 0) offsets[0] = 0;
+        return;
+    }
     const uint64_t v0 = (uint64_t)blockIdx.x * OFF_TILE;
     if (v0 >= p.count) return;  // uniform
     const uint64_t left = p.count - v0;
@@ -186,18 +194,33 @@ __global__ __launch_bounds__(OFF_THREADS) void offsets_write_kernel(const Decode
     __syncthreads();
     uint64_t run = chunk_base[blockIdx.x / SCAN_CHUNK] + tile_sums[blockIdx.x] + inc - mine;
     for (uint32_t k = 0; k < wave; k++) run += wtot[k];
-    uint64_t o[OFF_PER];
+    uint64_t o[OFF_PER + 1];
 #pragma unroll
-    for (int k = 0; k < OFF_PER; k++) { run += v[k]; o[k] = run; }
-    ZBRA_GLOBAL uint64_t *out = gptr_mut<uint64_t>(offsets) + v0 + 1 + j;
-    if (j + OFF_PER <= nv) {  // 32 contiguous bytes per lane, 2 KiB per wave
-        const u64x2 lo = {o[0], o[1]}, hi = {o[2], o[3]};
-        __builtin_nontemporal_store(lo, (ZBRA_GLOBAL u64x2 *)out);
-        __builtin_nontemporal_store(hi, (ZBRA_GLOBAL u64x2 *)(out + 2));
+    for (int k = 0; k < OFF_PER; k++) { o[k] = run; run += v[k]; }
+    o[OFF_PER] = run;
+    ZBRA_GLOBAL uint64_t *out = gptr_mut<uint64_t>(offsets) + v0 + j;
+    if ((wave + 1) * 64 * OFF_PER <= nv) {  // the wave's 256 offsets are all there (uniform within the wave)
+        // A lane holds 32 contiguous bytes, so a 16-byte store per lane would leave every other
+        // 16 bytes of the wave's 2 KiB to the next instruction; the wave turns its block around in
+        // LDS instead and each of its two store instructions writes a dense 1 KiB.
+        u64x2 *mine_t = turn[wave];
+        mine_t[lane * 2] = u64x2{o[0], o[1]};
+        mine_t[lane * 2 + 1] = u64x2{o[2], o[3]};
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        ZBRA_GLOBAL u64x2 *dst = (ZBRA_GLOBAL u64x2 *)(gptr_mut<uint64_t>(offsets) + v0 + wave * 64 * OFF_PER);
+        __builtin_nontemporal_store(mine_t[lane], dst + lane);
+        __builtin_nontemporal_store(mine_t[64 + lane], dst + 64 + lane);
     } else {
 #pragma unroll
         for (int k = 0; k < OFF_PER; k++)
             if (j + k < nv) out[k] = o[k];
+    }
+    if (v0 + nv == p.count) {  // the array ends in this tile: the total goes one past the last value
+#pragma unroll
+        for (int k = 0; k < OFF_PER; k++)
+            if (j + k + 1 == nv) out[k + 1] = o[k + 1];
     }
 }
 
