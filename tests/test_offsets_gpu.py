@@ -55,6 +55,25 @@ def test_offsets_match_cumsum(env, n):
         assert np.array_equal(got[1:n + 2].view(np.uint64), _want(lengths)), (n, int(e[12]))
 
 
+@pytest.mark.parametrize("w", list(range(1, 32)))
+def test_offsets_every_width(env, w):
+    """Every packed width, signed deltas around a non-zero midpoint, several tiles and a ragged last
+    one, payload at every byte alignment the test's padding reaches."""
+    torch, device, oc, _ = env
+    rng = np.random.default_rng(100 + w)
+    for n in (257, 2048 * 3 + 1, 20011):
+        half = 1 << (w - 1)
+        x = 1000 + rng.integers(-(half // 2), half - half // 2, n, dtype=np.int64)
+        x[rng.integers(0, n)] = 1000 - half // 2          # both ends of the range are present
+        x[rng.integers(0, n)] = 1000 + half - half // 2 - 1
+        e = oc.compress_int_array(x)
+        assert abs(int(e[12]) - w) <= 1
+        got, r = _run(torch, device, e, n, pad=(w + n) % 16)
+        assert r.status == 0 and r.out_count == n
+        assert got[0] == -7 and got[n + 2] == -7
+        assert np.array_equal(got[1:n + 2].view(np.uint64), _want(x)), (n, w, int(e[12]))
+
+
 def test_offsets_empty_rejected_and_crafted(env):
     torch, device, oc, L = env
     e = oc.compress_int_array(np.arange(10, dtype=np.int64))

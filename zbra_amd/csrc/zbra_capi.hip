@@ -798,7 +798,7 @@ int zbra_hip_decode_offsets_dev(const uint8_t *d_data, size_t len, size_t count,
     d.data = d_data; d.len = len; d.count = count; d.out = d_offsets + 1; d.kind = ZBRA_ELEM_I64; d.reserved = 0;
     hipLaunchKernelGGL(plan_decode_one_kernel, dim3(1), dim3(64), 0, stream, d, ntiles, plan, tile_start, d_result);
     if (ntiles) {
-        hipLaunchKernelGGL(offsets_sums_kernel, dim3((unsigned)((ntiles + OFF_SUM_TILES - 1) / OFF_SUM_TILES)), dim3(OFF_THREADS), 0, stream, plan,
+        hipLaunchKernelGGL(offsets_sums_kernel, dim3((unsigned)((ntiles + OFF_SUM_WAVES - 1) / OFF_SUM_WAVES)), dim3(64 * OFF_SUM_WAVES), 0, stream, plan,
                            tile_sums);
         hipLaunchKernelGGL(offsets_scan_chunks_kernel, dim3((unsigned)nchunks), dim3(SCAN_CHUNK), 0, stream, plan, tile_sums, chunk_base);
         hipLaunchKernelGGL(offsets_scan_totals_kernel, dim3(1), dim3(SCAN_CHUNK), 0, stream, plan, chunk_base);

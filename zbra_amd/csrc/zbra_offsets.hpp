@@ -60,54 +60,56 @@ __device__ __forceinline__ uint64_t wave_sum_u64(uint64_t v) {
     return v;
 }
 
-// 1. tile_sums[t] = sum of the tile's values.  A workgroup's life is one memory latency (load the
-// packed bytes, then reduce), so it takes OFF_SUM_TILES consecutive tiles at once: all their loads
-// are in flight together and the latency is paid once per OFF_SUM_TILES tiles.
-constexpr int OFF_SUM_TILES = 4;
-__global__ __launch_bounds__(OFF_THREADS) void offsets_sums_kernel(const DecodePlan *__restrict__ plan, uint64_t *__restrict__ tile_sums) {
-    __shared__ __attribute__((aligned(16))) uint32_t lds[OFF_SUM_TILES][lds_dwords<OFF_TILE>()];
-    __shared__ uint64_t wsum[OFF_SUM_TILES][OFF_WAVES];
+// 1. tile_sums[t] = sum of the tile's values.  The order of a sum does not matter, so nothing is
+// staged or transposed: one wave per tile, a lane takes whole 16-byte chunks of the packed bytes
+// (coalesced loads) and adds up the values that START in each of the chunk's four dwords, looking
+// one dword ahead for the value that straddles the end.  No LDS, no barriers: a wave's life is one
+// load latency and the waves of a SIMD overlap theirs freely.
+constexpr int OFF_SUM_WAVES = 4;  // tiles (= waves) per workgroup
+__global__ __launch_bounds__(64 * OFF_SUM_WAVES) void offsets_sums_kernel(const DecodePlan *__restrict__ plan, uint64_t *__restrict__ tile_sums) {
     const DecodePlan p = *plan;
-    const uint64_t t0 = (uint64_t)blockIdx.x * OFF_SUM_TILES;
-    if (t0 * OFF_TILE >= p.count) return;  // rejected or empty array: uniform
-    uint32_t nv[OFF_SUM_TILES], base_bits[OFF_SUM_TILES];
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint64_t t = (uint64_t)blockIdx.x * OFF_SUM_WAVES + (threadIdx.x >> 6);
+    const uint64_t v0 = t * OFF_TILE;
+    if (v0 >= p.count) return;  // rejected or empty array, or past the last tile: uniform within the wave
+    const uint64_t left = p.count - v0;
+    const uint32_t nv = left < (uint64_t)OFF_TILE ? (uint32_t)left : (uint32_t)OFF_TILE;
+    const uint32_t w = p.width;
+    uint64_t sum = 0;  // of the deltas; the midpoints are added at the end
+    if (w - 1u < 31u) {
+        const PackedSpan sp = packed_span(p, v0, nv);
+        const uint32_t mask = (1u << w) - 1u;
+        // n / w == (n * magic) >> 21 for n < 2^16: magic * w - 2^21 < w <= 31 and n * 31 < 2^21.
+        // n is a bit offset inside the tile's chunks, below 128 * (16 * 31 + 1) + 31 < 2^16.
+        const uint64_t magic = ((1u << 21) + w - 1u) / w;
+        const uint32_t end_bits = sp.base_bits + nv * w;  // one past the tile's last bit, counted from A0
+        const uintptr_t last = ((uintptr_t)p.payload + p.avail - 1) & ~(uintptr_t)15;  // chunk of the last payload byte
+        for (uint32_t c = lane; c < sp.nchunks; c += 64) {
+            const uintptr_t a = sp.A0 + (uintptr_t)c * 16;
+            const u32x4 x = ld_stream<1>(gptr<u32x4>(a));
+            const uint32_t ahead = a + 16 <= last ? ld_stream<1>(gptr<uint32_t>(a + 16)) : 0u;
+            const uint32_t d[5] = {x.x, x.y, x.z, x.w, ahead};
 #pragma unroll
-    for (int q = 0; q < OFF_SUM_TILES; q++) {
-        const uint64_t v0 = (t0 + q) * OFF_TILE;
-        nv[q] = 0; base_bits[q] = 0;
-        if (v0 < p.count) {
-            const uint64_t left = p.count - v0;
-            nv[q] = left < (uint64_t)OFF_TILE ? (uint32_t)left : (uint32_t)OFF_TILE;
-            if (p.width - 1u < 31u) {
-                const PackedSpan sp = packed_span(p, v0, nv[q]);
-                const ZBRA_GLOBAL u32x4 *src = gptr<u32x4>(sp.A0);
-                u32x4 *dst = (u32x4 *)lds[q];
-                for (uint32_t c = threadIdx.x; c < sp.nchunks; c += OFF_THREADS) dst[c] = ld_stream<1>(src + c);
-                base_bits[q] = sp.base_bits;
+            for (int q = 0; q < 4; q++) {
+                const uint32_t lo = c * 128u + q * 32u;  // first bit of dword q, counted from A0
+                // first value that starts at or after lo, and where in the dword it starts
+                const uint32_t k = lo > sp.base_bits ? (uint32_t)(((lo - sp.base_bits + w - 1u) * magic) >> 21) : 0u;
+                uint32_t s = sp.base_bits + k * w - lo;
+                const uint32_t lim = end_bits > lo ? (end_bits - lo < 32u ? end_bits - lo : 32u) : 0u;
+                // at most two 31-bit values start in one dword, |delta| <= 2^30 each: no overflow
+                int32_t acc = 0;
+                for (; s < lim; s += w) acc += zigzag_decode32(__builtin_amdgcn_alignbit(d[q + 1], d[q], s) & mask);
+                sum += (uint64_t)(int64_t)acc;
             }
         }
-    }
-    __syncthreads();
-#pragma unroll
-    for (int q = 0; q < OFF_SUM_TILES; q++) {
-        uint64_t sum = 0;
-        if (nv[q]) {
-            uint64_t v[OFF_PER];
-            offsets_values(p, (t0 + q) * OFF_TILE, nv[q], base_bits[q], lds[q], threadIdx.x * OFF_PER, v);
-            sum = (v[0] + v[1]) + (v[2] + v[3]);
+    } else if (w >= 32) {  // raw u64, a value with missing bytes reads as 0 (compression.rs:195-207)
+        for (uint32_t j = lane; j < nv; j += 64) {
+            const uint64_t off = (v0 + j) * 8;
+            sum += (uint64_t)zigzag_decode64(off + 8 <= p.avail ? load_le64_bytes(p.payload + off) : 0);
         }
-        sum = wave_sum_u64(sum);
-        if ((threadIdx.x & 63) == 0) wsum[q][threadIdx.x >> 6] = sum;
-    }
-    __syncthreads();
-#pragma unroll
-    for (int q = 0; q < OFF_SUM_TILES; q++)
-        if (threadIdx.x == (uint32_t)q && nv[q]) {
-            uint64_t t = 0;
-#pragma unroll
-            for (int k = 0; k < OFF_WAVES; k++) t += wsum[q][k];
-            tile_sums[t0 + q] = t;
-        }
+    }  // width byte 0: every delta is 0 (compression.rs:187-189)
+    sum = wave_sum_u64(sum);
+    if (lane == 0) tile_sums[t] = sum + (uint64_t)nv * (uint64_t)p.midpoint;
 }
 
 // 2. Exclusive scan of the tile sums in two levels: every workgroup scans one chunk of SCAN_CHUNK
