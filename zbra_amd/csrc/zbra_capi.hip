@@ -231,7 +231,8 @@ static int encode_batch_dev(DeviceCtx *ctx, const EncodeItem *items, size_t nd, 
     const size_t off_list = align_up(off_ts + (nd + 1) * sizeof(uint64_t), 64);  // arrays that may need select passes
     const size_t off_hist = align_up(off_list + nd * sizeof(uint32_t), 256);
     const size_t off_ctr = off_hist + nd * BINS * sizeof(uint32_t);  // zeroed together with the histograms
-    const size_t total = off_ctr + nd * sizeof(BracketCounters);
+    const size_t off_pend = off_ctr + nd * sizeof(BracketCounters);  // {count, arrays...} left to the pass-per-launch select; zeroed too
+    const size_t total = off_pend + (nd + 1) * sizeof(uint32_t);
     // candidate lists of the bracket select: CAND_SEGS segments, n/CAND_DIV values in all, per array
     // that is long enough for it
     const bool bracket = encode_bracket_enabled();
@@ -246,7 +247,7 @@ static int encode_batch_dev(DeviceCtx *ctx, const EncodeItem *items, size_t nd, 
     EncodeJob *h_jobs = (EncodeJob *)s->host;
     uint64_t *h_ts = (uint64_t *)((char *)s->host + off_ts);
     uint32_t *h_list = (uint32_t *)((char *)s->host + off_list);
-    uint32_t n_list = 0;
+    uint32_t n_list = 0, n_big = 0;  // n_big: listed arrays that one workgroup may not be able to finish
     uint64_t run = 0;
     size_t scratch_off = 0;
     for (size_t i = 0; i < nd; i++) {
@@ -265,12 +266,17 @@ static int encode_batch_dev(DeviceCtx *ctx, const EncodeItem *items, size_t nd, 
         h_ts[i] = run;
         run += tiles_of(items[i].n);
         // arrays of up to SAMPLE values are sorted whole by the sample kernel and need no pass
-        if (items[i].n && items[i].kind != KIND_U64_PLAIN && (!bracket || items[i].n > (uint64_t)SAMPLE)) h_list[n_list++] = (uint32_t)i;
+        if (items[i].n && items[i].kind != KIND_U64_PLAIN && (!bracket || items[i].n > (uint64_t)SAMPLE)) {
+            h_list[n_list++] = (uint32_t)i;
+            // what the select of an array reads is never longer than the array
+            if (items[i].n > SMALL_SRC_MAX) n_big++;
+        }
     }
     h_ts[nd] = run;
     const uint64_t ntiles = run;
     EncodeJob *d_jobs = (EncodeJob *)s->dev;
     const uint32_t *d_list = (const uint32_t *)((char *)s->dev + off_list);
+    uint32_t *d_pend = (uint32_t *)((char *)s->dev + off_pend);
     const uint64_t *d_ts = (const uint64_t *)((char *)s->dev + off_ts);
     uint32_t *d_hist = (uint32_t *)((char *)s->dev + off_hist);
     int st = hip_status(hipMemcpyAsync(s->dev, s->host, off_list + nd * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
@@ -281,13 +287,8 @@ static int encode_batch_dev(DeviceCtx *ctx, const EncodeItem *items, size_t nd, 
         // of a thousand arrays prefer 2048 (config 3: 5.41 ms against 5.69 at 1024).
         const unsigned gs = grid_for(ntiles, nd == 1 ? STREAM_GRID_CAP / 2 : STREAM_GRID_CAP);
         const unsigned ga = (unsigned)((nd + 255) / 256);
-        // workgroups per listed array in the select passes: about 4096 in all, at least 8 each
-        const uint32_t per_array = n_list ? (n_list >= 512 ? 8u : 4096u / n_list) : 1u;
-        // Tiles a select-pass workgroup reads before it merges its 4096 counters into the array's
-        // histogram (device-scope atomics).  One 2^27-value array with a wide bracket: a real pass
-        // takes 142 us at 1.5 tiles per workgroup (4096 workgroups), 62 us at 4, 44 us at 16, 115 us
-        // at 64; a thousand arrays keep all their workgroups busy at 4 and slow down beyond.
-        const uint32_t hist_tiles_per_wg = n_list <= 4 ? 16u : 4u;
+        // workgroups of a pass-per-launch histogram pass, dealt to the arrays still pending
+        const unsigned gh = n_big >= 512 ? 8192u : 4096u;
         if (ntiles) {
             hipLaunchKernelGGL(enc_sample_kernel, dim3((unsigned)nd), dim3(SAMPLE_THREADS), 0, stream, d_jobs, (uint32_t)nd,
                                bracket ? 1u : 0u);
@@ -299,13 +300,24 @@ static int encode_batch_dev(DeviceCtx *ctx, const EncodeItem *items, size_t nd, 
         }
         hipLaunchKernelGGL(enc_setup_kernel, dim3((unsigned)nd), dim3(THREADS), 0, stream, d_jobs, (uint32_t)nd, d_hist);
         if (ntiles) {
-            for (uint32_t pass = 0; n_list && pass < (uint32_t)MAX_PASSES; pass++) {
-                hipLaunchKernelGGL(enc_hist_kernel, dim3(n_list * per_array), dim3(THREADS), 0, stream, d_jobs, d_list, n_list,
-                                   per_array, hist_tiles_per_wg, d_hist, pass);
-                hipLaunchKernelGGL(enc_select_kernel, dim3((unsigned)nd), dim3(THREADS), 0, stream, d_jobs, d_hist, pass);
+            // every listed array whose select reads few enough keys is finished by one workgroup in
+            // one launch and the others are put on the pending list; the pass-per-launch kernels
+            // are only launched when an array could be too long for that (its length says so),
+            // and end at their first load when none was
+            if (n_list)
+                hipLaunchKernelGGL(enc_select_small_kernel, dim3(n_list), dim3(THREADS), 0, stream, d_jobs, d_list, n_list, d_hist, d_pend);
+            for (uint32_t pass = 0; n_big && pass < (uint32_t)MAX_PASSES; pass++) {
+                hipLaunchKernelGGL(enc_hist_kernel, dim3(gh), dim3(THREADS), 0, stream, d_jobs, d_pend, d_hist, pass);
+                hipLaunchKernelGGL(enc_select_kernel, dim3(n_big), dim3(THREADS), 0, stream, d_jobs, d_pend, d_hist, pass);
             }
-            if (mode == ENCODE_FULL)
-                hipLaunchKernelGGL(enc_or_kernel, dim3(gs), dim3(THREADS), 0, stream, d_jobs, d_ts, (uint32_t)nd, ntiles);
+            if (mode == ENCODE_FULL) {
+                // Few arrays of a batch need this pass (a span of 2^63 or more), and a contiguous
+                // run per resident workgroup would leave each of them to the two or three
+                // workgroups whose runs it crosses: short runs of 16 tiles instead, most of which
+                // end at their first look (a thousand 2^20-row arrays, two of them wide: 187 -> 47 us).
+                const unsigned go = nd == 1 ? gs : grid_for(ntiles / 16 + 1, 32768);
+                hipLaunchKernelGGL(enc_or_kernel, dim3(go), dim3(THREADS), 0, stream, d_jobs, d_ts, (uint32_t)nd, ntiles);
+            }
         }
         if (mode == ENCODE_FULL) {
             if (frames)

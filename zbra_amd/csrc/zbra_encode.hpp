@@ -89,8 +89,8 @@ enum SelectMode : uint32_t {
 
 constexpr int SAMPLE = 4096;          // sample keys sorted in LDS (32 KiB)
 constexpr int SAMPLE_THREADS = 1024;  // lanes of the sorting workgroup
-constexpr int SAMPLE_MARGIN = 192;    // sample ranks either side: 6 sigma, sigma = sqrt(SAMPLE)/2 = 32
-constexpr int CAND_DIV = 4;           // candidate list capacity = n / CAND_DIV (a bracket holds ~9 % of n)
+constexpr int SAMPLE_MARGIN = 128;    // sample ranks either side: 4 sigma, sigma = sqrt(SAMPLE)/2 = 32
+constexpr int CAND_DIV = 4;           // candidate list capacity = n / CAND_DIV (a bracket holds ~6 % of n)
 constexpr int CAND_LDS = 2048;        // candidates a workgroup stages in LDS between flushes (>= 1 tile)
 
 __device__ __forceinline__ int64_t load_value(const EncodeJob &j, uint64_t i) {
@@ -211,7 +211,7 @@ __device__ __forceinline__ void set_midpoint(EncodeJob &j, int64_t a, int64_t b,
 
 // ---- 1. sample: bracket the median (or finish small arrays outright) --------------------------
 
-// Bitonic sort of SAMPLE keys in LDS by one workgroup of SAMPLE_THREADS lanes.
+// Bitonic sort of up to SAMPLE keys in LDS by one workgroup of TH lanes (a multiple of 64).
 //
 // Pair p of a stage compares elements lo = (p / stride) * 2 * stride + p % stride and lo + stride.
 // A wave owns 64 consecutive pairs, so in a stage with stride <= 64 it touches exactly the 128
@@ -219,6 +219,7 @@ __device__ __forceinline__ void set_midpoint(EncodeJob &j, int64_t a, int64_t b,
 // barrier, only the wave's own LDS ordering (20 barriers instead of 78 for 4096 keys).
 // Sorts the first m keys (m a power of two, 2 <= m <= SAMPLE): a short array only pays for its
 // own length, not for the full sample.
+template <int TH>
 __device__ __forceinline__ void sort_keys_lds(uint64_t *sk, uint32_t m) {
     uint32_t prev_stride = 128;  // the keys were written by other waves
     for (uint32_t size = 2; size <= m; size <<= 1) {
@@ -231,7 +232,7 @@ __device__ __forceinline__ void sort_keys_lds(uint64_t *sk, uint32_t m) {
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
             }
             prev_stride = stride;
-            for (uint32_t t = threadIdx.x; t < m / 2; t += SAMPLE_THREADS) {
+            for (uint32_t t = threadIdx.x; t < m / 2; t += TH) {
                 const uint32_t lo = 2 * t - (t & (stride - 1));  // index of the lower partner
                 const uint32_t hi = lo + stride;
                 const bool up = (lo & size) == 0;
@@ -269,7 +270,7 @@ __global__ __launch_bounds__(SAMPLE_THREADS) void enc_sample_kernel(EncodeJob *_
         }
         sk[j] = key;
     }
-    sort_keys_lds(sk, m);
+    sort_keys_lds<SAMPLE_THREADS>(sk, m);
     if (threadIdx.x != 0) return;
     const uint64_t k = (n - 1) / 2;  // rank of a: n/2 - 1 for even n, n/2 for odd n
     if (whole) {
@@ -533,6 +534,8 @@ __global__ __launch_bounds__(THREADS) void enc_setup_kernel(EncodeJob *__restric
 // ---- 4. radix select ---------------------------------------------------------------------
 
 // Digit `pass` of key into the workgroup's LDS histogram, if the key shares the resolved prefix.
+// (Letting the lanes of a wave that hold the same bin send one atomic between them, for columns of
+// a few distinct values, made the one-workgroup select slower on every column shape tried.)
 __device__ __forceinline__ void hist_key(uint32_t *lh, uint64_t key, uint32_t pass, uint32_t shift, uint64_t prefix, bool last,
                                          uint64_t &above) {
     if (pass == 0) {
@@ -544,18 +547,9 @@ __device__ __forceinline__ void hist_key(uint32_t *lh, uint64_t key, uint32_t pa
     }
 }
 
-// Histogram of digit `pass` of the keys that share the resolved prefix, over what each array's
-// select reads: the whole array (tiles of TILE values) or its candidate list (segments, each
-// filled from its start).  `list` names the arrays that can need a pass at all (the host knows
-// which are too short to); workgroup (i, w) of `per_array` workgroups per listed array takes tiles
-// w, w + per_array, ... of array list[i], so an array that needs many passes is never left to the
-// two or three workgroups that happen to own its stretch of the submission.
-__global__ __launch_bounds__(THREADS) void enc_hist_kernel(EncodeJob *__restrict__ jobs, const uint32_t *__restrict__ list,
-                                                            uint32_t n_list, uint32_t per_array, uint32_t tiles_per_wg,
-                                                            uint32_t *__restrict__ hist, uint32_t pass) {
-    const uint32_t li = blockIdx.x / per_array, w = blockIdx.x % per_array;
-    if (li >= n_list) return;
-    const uint32_t a = list[li];
+// One workgroup's share (tiles w, w + per_array, ...) of one array's histogram pass.
+__device__ __forceinline__ void hist_one(EncodeJob *__restrict__ jobs, uint32_t a, uint32_t w, uint32_t per_array, uint32_t tiles_per_wg,
+                                         uint32_t *__restrict__ hist, uint32_t pass, uint32_t *lh) {
     const EncodeJob &job = jobs[a];
     const uint32_t mode = job.mode;
     if ((mode != SEL_FULL && mode != SEL_BRACKET_COMPACT) || pass >= job.passes) return;
@@ -563,10 +557,11 @@ __global__ __launch_bounds__(THREADS) void enc_hist_kernel(EncodeJob *__restrict
     // device-scope atomics, which cost more than reading a tile: only as many workgroups take part
     // as have tiles_per_wg tiles each (a candidate list holds job.inb values).
     const uint64_t work_tiles = ((mode == SEL_FULL ? job.n : job.inb) + TILE - 1) / TILE;
+    if (tiles_per_wg == 0) tiles_per_wg = work_tiles >= 4096 ? 16u : work_tiles < 512 ? 2u : (uint32_t)(work_tiles / 256);
     const uint64_t want = work_tiles / tiles_per_wg;
     const uint32_t eff = want < 1 ? 1u : want < per_array ? (uint32_t)want : per_array;
     if (w >= eff) return;
-    __shared__ uint32_t lh[BINS];
+    __syncthreads();  // the previous item's merge has read lh
     for (uint32_t b = threadIdx.x; b < BINS; b += THREADS) lh[b] = 0;
     __syncthreads();
     const uint32_t shift = DIGIT_BITS * (job.passes - 1 - pass);
@@ -614,75 +609,275 @@ __global__ __launch_bounds__(THREADS) void enc_hist_kernel(EncodeJob *__restrict
     }
 }
 
-// One workgroup per array: finds the bin that holds rank k, descends, and on the last pass
-// derives a, b and the midpoint.  Leaves the array's histogram zeroed for the next pass.
-__global__ __launch_bounds__(THREADS) void enc_select_kernel(EncodeJob *__restrict__ jobs, uint32_t *__restrict__ hist,
-                                                              uint32_t pass) {
-    const uint32_t a = blockIdx.x;
-    EncodeJob &job = jobs[a];
-    if (pass >= job.passes) return;
-    __shared__ uint64_t part[THREADS];
-    __shared__ uint32_t sel_bin, next_bin, sel_cnt;
-    __shared__ uint64_t sel_before;
-    uint32_t *gh = hist + (size_t)a * BINS;
-    constexpr int PER = BINS / THREADS;  // 16 consecutive bins per thread
+// Histogram of digit `pass` of the keys that share the resolved prefix, over what each array's
+// select reads: the whole array (tiles of TILE values) or its candidate list (segments, each
+// filled from its start).  `pending` = {count, arrays...} names the arrays that still need passes
+// (written by enc_select_small_kernel: the host cannot know).  The grid is fixed; its workgroups
+// are dealt evenly to the pending arrays, workgroup w of an array's `per_array` taking tiles w,
+// w + per_array, ..., so that an array is never left to the two or three workgroups that happen
+// to own its stretch of the submission.
+__global__ __launch_bounds__(THREADS) void enc_hist_kernel(EncodeJob *__restrict__ jobs, const uint32_t *__restrict__ pending,
+                                                            uint32_t *__restrict__ hist, uint32_t pass) {
+    const uint32_t n_list = pending[0];
+    if (n_list == 0) return;
+    const uint32_t *list = pending + 1;
+    uint32_t per_array = gridDim.x / n_list;
+    if (per_array == 0) per_array = 1;
+    // Tiles a workgroup reads before it merges its 4096 counters into the array's histogram
+    // (device-scope atomics).  One 2^27-value array with a wide bracket: a real pass takes 142 us at
+    // 1.5 tiles per workgroup (4096 workgroups), 62 us at 4, 44 us at 16, 115 us at 64; a thousand
+    // arrays keep all their workgroups busy at 4 and slow down beyond.  0 = by the array's length:
+    // about 256 workgroups, 2 to 16 tiles each.
+    const uint32_t tiles_per_wg = n_list <= 4 ? 0u : 4u;
+    __shared__ uint32_t lh[BINS];
+    for (uint64_t item = blockIdx.x; item < (uint64_t)n_list * per_array; item += gridDim.x)  // uniform
+        hist_one(jobs, list[item / per_array], (uint32_t)(item % per_array), per_array, tiles_per_wg, hist, pass, lh);
+}
+
+// The bin that holds rank k of a BINS-bin histogram, found by one workgroup of THREADS lanes: lane
+// t brings bins [t * SEL_PER, +SEL_PER).  Every lane gets the same answer.
+constexpr int SEL_PER = BINS / THREADS;  // 16 consecutive bins per thread
+struct BinPick {
+    uint32_t bin, cnt;   // the bin of rank k and how many keys it holds
+    uint32_t next_bin;   // the next bin above it that holds a key (BINS if none); only when asked for
+    uint32_t pad;
+    uint64_t before;     // keys in the bins below
+};
+struct BinPickShared {
+    uint64_t part[THREADS];
+    BinPick pick;
+};
+__device__ __forceinline__ BinPick pick_bin(const uint32_t (&c)[SEL_PER], uint64_t k, bool want_next, BinPickShared *sh) {
     const uint32_t tid = threadIdx.x;
-    uint32_t c[PER];
     uint64_t sum = 0;
 #pragma unroll
-    for (int i = 0; i < PER; i++) { c[i] = gh[tid * PER + i]; sum += c[i]; }
-    part[tid] = sum;
-    if (tid == 0) next_bin = BINS;
+    for (int i = 0; i < SEL_PER; i++) sum += c[i];
+    __syncthreads();  // the previous use of `sh` is over
+    sh->part[tid] = sum;
+    if (tid == 0) sh->pick.next_bin = BINS;
     __syncthreads();
     // exclusive prefix of the per-thread sums (256 entries: a serial scan by every thread's own
     // loop would be 256 LDS reads; a Hillis-Steele scan is 8 steps)
     uint64_t incl = sum;
     for (int o = 1; o < THREADS; o <<= 1) {
-        uint64_t add = tid >= (uint32_t)o ? part[tid - o] : 0;
+        uint64_t add = tid >= (uint32_t)o ? sh->part[tid - o] : 0;
         __syncthreads();
         incl += add;
-        part[tid] = incl;
+        sh->part[tid] = incl;
         __syncthreads();
     }
-    uint64_t before = incl - sum;
-    const uint64_t k = job.k;
+    const uint64_t before = incl - sum;
     if (k >= before && k < incl) {  // exactly one thread
         uint64_t run = before;
 #pragma unroll
-        for (int i = 0; i < PER; i++) {
-            if (k >= run && k < run + c[i]) { sel_bin = tid * PER + i; sel_before = run; sel_cnt = c[i]; }
+        for (int i = 0; i < SEL_PER; i++) {
+            if (k >= run && k < run + c[i]) { sh->pick.bin = tid * SEL_PER + i; sh->pick.before = run; sh->pick.cnt = c[i]; }
             run += c[i];
         }
     }
     __syncthreads();
-    const uint32_t d = sel_bin;
-    const bool last = pass + 1 == job.passes;
-    if (last) {
+    if (want_next) {
+        const uint32_t d = sh->pick.bin;
 #pragma unroll
-        for (int i = 0; i < PER; i++) {
-            const uint32_t b = tid * PER + i;
-            if (b > d && c[i]) { atomicMin(&next_bin, b); break; }
+        for (int i = 0; i < SEL_PER; i++) {
+            const uint32_t b = tid * SEL_PER + i;
+            if (b > d && c[i]) { atomicMin(&sh->pick.next_bin, b); break; }
         }
+        __syncthreads();
     }
+    return sh->pick;
+}
+
+// a and b (the keys of rank k and, for an even count, of rank k + 1) are known: the midpoint.
+__device__ __forceinline__ void finish_select(EncodeJob &job, uint64_t key_a, uint64_t key_b) {
+    const int64_t va = (int64_t)((key_a + job.key_base) ^ SIGN);
+    const int64_t vb = (int64_t)((key_b + job.key_base) ^ SIGN);
+    set_midpoint(job, va, vb, (job.n & 1) == 0);
+}
+
+// One workgroup per pending array: finds the bin that holds rank k, descends, and on the last
+// pass derives a, b and the midpoint.  Leaves the array's histogram zeroed for the next pass.
+__global__ __launch_bounds__(THREADS) void enc_select_kernel(EncodeJob *__restrict__ jobs, const uint32_t *__restrict__ pending,
+                                                              uint32_t *__restrict__ hist, uint32_t pass) {
+    if (blockIdx.x >= pending[0]) return;
+    const uint32_t a = pending[1 + blockIdx.x];
+    EncodeJob &job = jobs[a];
+    if (pass >= job.passes) return;
+    __shared__ BinPickShared sh;
+    uint32_t *gh = hist + (size_t)a * BINS;
+    const uint32_t tid = threadIdx.x;
+    uint32_t c[SEL_PER];
 #pragma unroll
-    for (int i = 0; i < PER; i++) gh[tid * PER + i] = 0;
-    __syncthreads();
+    for (int i = 0; i < SEL_PER; i++) { c[i] = gh[tid * SEL_PER + i]; gh[tid * SEL_PER + i] = 0; }
+    const bool last = pass + 1 == job.passes;
+    const BinPick pk = pick_bin(c, job.k, last, &sh);
     if (tid == 0) {
         const uint64_t high = job.prefix;
-        const uint64_t key_a = pass == 0 ? (uint64_t)d : (high << DIGIT_BITS) | d;
-        const uint64_t k_in = k - sel_before;
+        const uint64_t key_a = pass == 0 ? (uint64_t)pk.bin : (high << DIGIT_BITS) | pk.bin;
+        const uint64_t k_in = job.k - pk.before;
         job.prefix = key_a;
         job.k = k_in;
         if (last) {
-            const bool even = (job.n & 1) == 0;
             uint64_t key_b = key_a;
-            if (even && k_in + 1 >= sel_cnt) {
-                if (next_bin < BINS) key_b = pass == 0 ? (uint64_t)next_bin : (high << DIGIT_BITS) | next_bin;
+            if ((job.n & 1) == 0 && k_in + 1 >= pk.cnt) {
+                if (pk.next_bin < (uint32_t)BINS) key_b = pass == 0 ? (uint64_t)pk.next_bin : (high << DIGIT_BITS) | pk.next_bin;
                 else key_b = job.next_above;
             }
-            const int64_t va = (int64_t)((key_a + job.key_base) ^ SIGN);
-            const int64_t vb = (int64_t)((key_b + job.key_base) ^ SIGN);
-            set_midpoint(job, va, vb, even);
+            finish_select(job, key_a, key_b);
+        }
+    }
+}
+
+// ---- 4b. short select sources: one workgroup per array, every pass in one launch ---------------
+
+// f(key) for every key of what the array's select reads, by the whole workgroup.  One workgroup
+// reading tile after tile would pay a full memory latency per tile, so four tiles (of the array,
+// or of four segments of the candidate list) are loaded before the first is looked at.
+constexpr int SEL_AHEAD = 4;
+static_assert(CAND_SEGS % SEL_AHEAD == 0, "segments are read in groups");
+template <typename F>
+__device__ __forceinline__ void for_each_select_key(const EncodeJob &job, uint32_t mode, F &&f) {
+    const uint64_t base = job.key_base;
+    int64_t x[SEL_AHEAD][2 * PAIRS];
+    if (mode == SEL_FULL) {
+        const void *values = job.values;
+        const uint32_t kind = job.kind;
+        const uint64_t n = job.n;
+        for (uint64_t v0 = 0; v0 < n; v0 += (uint64_t)SEL_AHEAD * TILE) {
+#pragma unroll
+            for (int u = 0; u < SEL_AHEAD; u++)
+                if (v0 + (uint64_t)u * TILE < n) load_tile_from(values, kind, v0 + (uint64_t)u * TILE, n, 0, x[u]);
+#pragma unroll
+            for (int u = 0; u < SEL_AHEAD; u++) {
+                const uint64_t t0 = v0 + (uint64_t)u * TILE;
+                if (t0 < n) {
+#pragma unroll
+                    for (int e = 0; e < 2 * PAIRS; ++e)
+                        if (t0 + tile_slot(kind, e) < n) f(((uint64_t)x[u][e] ^ SIGN) - base);
+                }
+            }
+        }
+    } else {
+        for (uint32_t g = 0; g < (uint32_t)CAND_SEGS; g += SEL_AHEAD) {
+            uint64_t end[SEL_AHEAD], longest = 0;  // setup made sure that no segment overflowed
+#pragma unroll
+            for (int u = 0; u < SEL_AHEAD; u++) {
+                end[u] = job.counters->slot[g + u].cand_count;
+                longest = end[u] > longest ? end[u] : longest;
+            }
+            for (uint64_t v0 = 0; v0 < longest; v0 += TILE) {
+#pragma unroll
+                for (int u = 0; u < SEL_AHEAD; u++)
+                    if (v0 < end[u]) load_tile_from(job.cand + (size_t)(g + u) * job.seg_cap, ZBRA_ELEM_I64, v0, end[u], 0, x[u]);
+#pragma unroll
+                for (int u = 0; u < SEL_AHEAD; u++) {
+                    if (v0 < end[u]) {
+#pragma unroll
+                        for (int e = 0; e < 2 * PAIRS; ++e)
+                            if (v0 + tile_slot(ZBRA_ELEM_I64, e) < end[u]) f(((uint64_t)x[u][e] ^ SIGN) - base);
+                    }
+                }
+            }
+        }
+    }
+}
+
+// Arrays whose select reads at most SMALL_SRC_MAX keys (a candidate list, a short array, or
+// nothing at all when the bracket pass already filled the histogram) are finished here by one
+// workgroup each, with the histogram in LDS and no device-scope atomic: the pass-per-launch kernels
+// above merge up to BINS counters per workgroup into global memory and read the source once per
+// digit (a thousand arrays of 2^20 values: 0.79 ms for the six pairs of launches, 0.34 ms here).  After the first digit the keys that share it
+// are usually a handful: as soon as KEEP or fewer are left they are gathered into LDS and sorted,
+// so the source is read twice, not once per digit.  Arrays with a longer source are put on the
+// `pending` list ({count, arrays...}, zero on entry) of the pass-per-launch kernels, untouched.
+constexpr uint64_t SMALL_SRC_MAX = 1ull << 19;
+constexpr uint32_t KEEP = 2048;  // 16 KiB: with the histogram and the scan, four workgroups fit a CU
+__global__ __launch_bounds__(THREADS) void enc_select_small_kernel(EncodeJob *__restrict__ jobs, const uint32_t *__restrict__ list,
+                                                                    uint32_t n_list, uint32_t *__restrict__ hist,
+                                                                    uint32_t *__restrict__ pending) {
+    if (blockIdx.x >= n_list) return;
+    const uint32_t a = list[blockIdx.x];
+    EncodeJob &job = jobs[a];
+    const uint32_t passes = job.passes, mode = job.mode;
+    if (passes == 0 || mode == SEL_DONE) return;
+    const uint64_t src_n = mode == SEL_FULL ? job.n : mode == SEL_BRACKET_COMPACT ? job.inb : 0;
+    if (src_n > SMALL_SRC_MAX) {  // too long for one workgroup: onto the list of the pass-per-launch kernels
+        if (threadIdx.x == 0) pending[1 + atomicAdd(&pending[0], 1u)] = a;
+        return;
+    }
+    __shared__ uint32_t lh[BINS];
+    __shared__ uint64_t keep[KEEP];
+    __shared__ BinPickShared sh;
+    __shared__ uint32_t keep_n;
+    __shared__ unsigned long long above_all;
+    const uint32_t tid = threadIdx.x;
+    const bool even = (job.n & 1) == 0;
+    uint64_t prefix = 0, k = job.k;
+    for (uint32_t pass = 0; pass < passes; ++pass) {  // uniform
+        const uint32_t shift = DIGIT_BITS * (passes - 1 - pass);
+        const bool last = pass + 1 == passes;
+        uint64_t above = ~0ull;
+        if (mode == SEL_BRACKET_HIST) {  // one pass, histogram already counted
+            uint32_t *gh = hist + (size_t)a * BINS;
+            for (uint32_t b = tid; b < (uint32_t)BINS; b += THREADS) { lh[b] = gh[b]; gh[b] = 0; }
+        } else {
+            for (uint32_t b = tid; b < (uint32_t)BINS; b += THREADS) lh[b] = 0;
+            __syncthreads();
+            for_each_select_key(job, mode, [&](uint64_t key) { hist_key(lh, key, pass, shift, prefix, last, above); });
+        }
+        if (tid == 0) above_all = ~0ull;
+        __syncthreads();
+        uint32_t c[SEL_PER];
+#pragma unroll
+        for (int i = 0; i < SEL_PER; i++) c[i] = lh[tid * SEL_PER + i];
+        const BinPick pk = pick_bin(c, k, last, &sh);
+        const uint64_t high = prefix;
+        prefix = pass == 0 ? (uint64_t)pk.bin : (high << DIGIT_BITS) | pk.bin;
+        k -= pk.before;
+        if (last) {
+            above = wave_min_u64(above);
+            if ((tid & 63) == 0 && above != ~0ull) atomicMin(&above_all, (unsigned long long)above);
+            __syncthreads();
+            if (tid == 0) {
+                uint64_t key_b = prefix;
+                if (even && k + 1 >= pk.cnt) {
+                    if (pk.next_bin < (uint32_t)BINS) key_b = pass == 0 ? (uint64_t)pk.next_bin : (high << DIGIT_BITS) | pk.next_bin;
+                    else key_b = above_all < job.next_above ? (uint64_t)above_all : job.next_above;
+                }
+                finish_select(job, prefix, key_b);
+                job.passes = 0;
+            }
+            return;
+        }
+        if (pk.cnt <= KEEP) {
+            // gather the keys that share the resolved digits, sort them, read a and b off the list
+            if (tid == 0) keep_n = 0;
+            __syncthreads();
+            above = ~0ull;
+            for_each_select_key(job, mode, [&](uint64_t key) {
+                const uint64_t h = key >> shift;
+                if (h == prefix) keep[atomicAdd(&keep_n, 1u)] = key;
+                else if (h > prefix) above = min(above, key);
+            });
+            above = wave_min_u64(above);
+            if ((tid & 63) == 0 && above != ~0ull) atomicMin(&above_all, (unsigned long long)above);
+            __syncthreads();
+            const uint32_t cnt = pk.cnt;  // == keep_n
+            uint32_t m = 2;
+            while (m < cnt) m <<= 1;
+            for (uint32_t i = cnt + tid; i < m; i += THREADS) keep[i] = ~0ull;  // padding sorts to the end
+            sort_keys_lds<THREADS>(keep, m);
+            if (tid == 0) {
+                const uint64_t key_a = keep[k];
+                uint64_t key_b = key_a;
+                if (even) {
+                    if (k + 1 < cnt) key_b = keep[k + 1];
+                    else key_b = above_all < job.next_above ? (uint64_t)above_all : job.next_above;
+                }
+                finish_select(job, key_a, key_b);
+                job.passes = 0;
+            }
+            return;
         }
     }
 }
