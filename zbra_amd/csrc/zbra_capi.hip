@@ -137,6 +137,16 @@ static bool encode_bracket_enabled() {
     return on;
 }
 
+// Longest select source (keys) that one workgroup finishes on its own (ZBRA_HIP_SMALL_SELECT_KEYS).
+static uint64_t small_select_keys() {
+    static const uint64_t v = [] {
+        const char *e = getenv("ZBRA_HIP_SMALL_SELECT_KEYS");
+        const long long x = e ? atoll(e) : 0;
+        return x > 0 ? (uint64_t)x : SMALL_SRC_MAX;
+    }();
+    return v;
+}
+
 static unsigned pack_grid_cap() {
     static const unsigned cap = [] {
         const char *e = getenv("ZBRA_HIP_PACK_GRID");
@@ -247,6 +257,7 @@ static int encode_batch_dev(DeviceCtx *ctx, const EncodeItem *items, size_t nd, 
     EncodeJob *h_jobs = (EncodeJob *)s->host;
     uint64_t *h_ts = (uint64_t *)((char *)s->host + off_ts);
     uint32_t *h_list = (uint32_t *)((char *)s->host + off_list);
+    const uint64_t small_max = small_select_keys();
     uint32_t n_list = 0, n_big = 0;  // n_big: listed arrays that one workgroup may not be able to finish
     uint64_t run = 0;
     size_t scratch_off = 0;
@@ -269,7 +280,7 @@ static int encode_batch_dev(DeviceCtx *ctx, const EncodeItem *items, size_t nd, 
         if (items[i].n && items[i].kind != KIND_U64_PLAIN && (!bracket || items[i].n > (uint64_t)SAMPLE)) {
             h_list[n_list++] = (uint32_t)i;
             // what the select of an array reads is never longer than the array
-            if (items[i].n > SMALL_SRC_MAX) n_big++;
+            if (items[i].n > small_max) n_big++;
         }
     }
     h_ts[nd] = run;
@@ -305,7 +316,7 @@ static int encode_batch_dev(DeviceCtx *ctx, const EncodeItem *items, size_t nd, 
             // are only launched when an array could be too long for that (its length says so),
             // and end at their first load when none was
             if (n_list)
-                hipLaunchKernelGGL(enc_select_small_kernel, dim3(n_list), dim3(THREADS), 0, stream, d_jobs, d_list, n_list, d_hist, d_pend);
+                hipLaunchKernelGGL(enc_select_small_kernel, dim3(n_list), dim3(THREADS), 0, stream, d_jobs, d_list, n_list, d_hist, d_pend, small_max);
             for (uint32_t pass = 0; n_big && pass < (uint32_t)MAX_PASSES; pass++) {
                 hipLaunchKernelGGL(enc_hist_kernel, dim3(gh), dim3(THREADS), 0, stream, d_jobs, d_pend, d_hist, pass);
                 hipLaunchKernelGGL(enc_select_kernel, dim3(n_big), dim3(THREADS), 0, stream, d_jobs, d_pend, d_hist, pass);

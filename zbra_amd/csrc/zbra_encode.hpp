@@ -782,26 +782,28 @@ __device__ __forceinline__ void for_each_select_key(const EncodeJob &job, uint32
     }
 }
 
-// Arrays whose select reads at most SMALL_SRC_MAX keys (a candidate list, a short array, or
+// Arrays whose select reads at most `small_max` keys (a short candidate list, a short array, or
 // nothing at all when the bracket pass already filled the histogram) are finished here by one
-// workgroup each, with the histogram in LDS and no device-scope atomic: the pass-per-launch kernels
-// above merge up to BINS counters per workgroup into global memory and read the source once per
-// digit (a thousand arrays of 2^20 values: 0.79 ms for the six pairs of launches, 0.34 ms here).  After the first digit the keys that share it
-// are usually a handful: as soon as KEEP or fewer are left they are gathered into LDS and sorted,
-// so the source is read twice, not once per digit.  Arrays with a longer source are put on the
-// `pending` list ({count, arrays...}, zero on entry) of the pass-per-launch kernels, untouched.
-constexpr uint64_t SMALL_SRC_MAX = 1ull << 19;
+// workgroup each: histogram in LDS, no device-scope atomic, and after the first digit the keys
+// that share it are usually a handful: as soon as KEEP or fewer are left they are gathered into
+// LDS and sorted, so the source is read twice, not once per digit.  Arrays with a longer source
+// are put on the `pending` list ({count, arrays...}, zero on entry) of the pass-per-launch kernels,
+// untouched: one workgroup reads at about 11 GB/s, so a long list is better spread over many.
+// Measured thresholds (2^12 .. 2^19 keys): a thousand 2^20-row arrays encode in 4.73-4.85 ms
+// whatever it is; 1152 ragged columns of up to 2^21 rows 6.31 ms up to 2^14 against 6.55 ms at
+// 2^19; 96 columns of 2^22 rows 2.37 against 2.54 ms.
+constexpr uint64_t SMALL_SRC_MAX = 1ull << 14;  // default of the `small_max` argument
 constexpr uint32_t KEEP = 2048;  // 16 KiB: with the histogram and the scan, four workgroups fit a CU
 __global__ __launch_bounds__(THREADS) void enc_select_small_kernel(EncodeJob *__restrict__ jobs, const uint32_t *__restrict__ list,
                                                                     uint32_t n_list, uint32_t *__restrict__ hist,
-                                                                    uint32_t *__restrict__ pending) {
+                                                                    uint32_t *__restrict__ pending, uint64_t small_max) {
     if (blockIdx.x >= n_list) return;
     const uint32_t a = list[blockIdx.x];
     EncodeJob &job = jobs[a];
     const uint32_t passes = job.passes, mode = job.mode;
     if (passes == 0 || mode == SEL_DONE) return;
     const uint64_t src_n = mode == SEL_FULL ? job.n : mode == SEL_BRACKET_COMPACT ? job.inb : 0;
-    if (src_n > SMALL_SRC_MAX) {  // too long for one workgroup: onto the list of the pass-per-launch kernels
+    if (src_n > small_max) {  // too long for one workgroup: onto the list of the pass-per-launch kernels
         if (threadIdx.x == 0) pending[1 + atomicAdd(&pending[0], 1u)] = a;
         return;
     }
