@@ -258,6 +258,8 @@ static int encode_batch_dev(DeviceCtx *ctx, const EncodeItem *items, size_t nd, 
     uint64_t *h_ts = (uint64_t *)((char *)s->host + off_ts);
     uint32_t *h_list = (uint32_t *)((char *)s->host + off_list);
     const uint64_t small_max = small_select_keys();
+    // digits a pending array can have: u32 inputs span less than 2^32, three digits of twelve bits
+    uint32_t big_passes = (32 + DIGIT_BITS - 1) / DIGIT_BITS;
     uint32_t n_list = 0, n_big = 0;  // n_big: listed arrays that one workgroup may not be able to finish
     uint64_t run = 0;
     size_t scratch_off = 0;
@@ -280,7 +282,10 @@ static int encode_batch_dev(DeviceCtx *ctx, const EncodeItem *items, size_t nd, 
         if (items[i].n && items[i].kind != KIND_U64_PLAIN && (!bracket || items[i].n > (uint64_t)SAMPLE)) {
             h_list[n_list++] = (uint32_t)i;
             // what the select of an array reads is never longer than the array
-            if (items[i].n > small_max) n_big++;
+            if (items[i].n > small_max) {
+                n_big++;
+                if (items[i].kind != ZBRA_ELEM_U32) big_passes = (uint32_t)MAX_PASSES;
+            }
         }
     }
     h_ts[nd] = run;
@@ -317,7 +322,7 @@ static int encode_batch_dev(DeviceCtx *ctx, const EncodeItem *items, size_t nd, 
             // and end at their first load when none was
             if (n_list)
                 hipLaunchKernelGGL(enc_select_small_kernel, dim3(n_list), dim3(THREADS), 0, stream, d_jobs, d_list, n_list, d_hist, d_pend, small_max);
-            for (uint32_t pass = 0; n_big && pass < (uint32_t)MAX_PASSES; pass++) {
+            for (uint32_t pass = 0; n_big && pass < big_passes; pass++) {
                 hipLaunchKernelGGL(enc_hist_kernel, dim3(gh), dim3(THREADS), 0, stream, d_jobs, d_pend, d_hist, pass);
                 hipLaunchKernelGGL(enc_select_kernel, dim3(n_big), dim3(THREADS), 0, stream, d_jobs, d_pend, d_hist, pass);
             }
