@@ -858,7 +858,10 @@ __global__ __launch_bounds__(THREADS) void enc_select_small_kernel(EncodeJob *__
             above = ~0ull;
             for_each_select_key(job, mode, [&](uint64_t key) {
                 const uint64_t h = key >> shift;
-                if (h == prefix) keep[atomicAdd(&keep_n, 1u)] = key;
+                if (h == prefix) {
+                    const uint32_t at = atomicAdd(&keep_n, 1u);
+                    if (at < KEEP) keep[at] = key;  // always true while nobody writes the source
+                }
                 else if (h > prefix) above = min(above, key);
             });
             above = wave_min_u64(above);
