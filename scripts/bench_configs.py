@@ -1,9 +1,14 @@
 #!/usr/bin/env python3
-"""Decode rates of the other device-resident configurations on ONE GPU (parity cases, not bench
-lines): 3 = mixed per-array widths, 1e9 rows in 2^20-row arrays; 4 = one GPU's share of the
-sum-typed table (2^29 rows as Blocks of 2^22: enum tags + two Int columns per variant).
-Everything is generated, encoded (batched) and decoded (batched) on the device; the check is the
-exact round trip.  Prints one JSON line per configuration."""
+"""Decode rates of the other device-resident configurations (parity cases, not bench lines):
+3 = mixed per-array widths, 1e9 rows in 2^20-row arrays; 4 = the sum-typed table, 2^29 rows per
+GPU as Blocks of 2^22 (enum tags + two Int columns per variant).  Everything is generated,
+encoded (batched) and decoded (batched) on the device; the check is the exact round trip.  Prints
+one JSON line per configuration.
+
+Under torch.distributed.run (one process per GPU) config 4 deals Block b of the 128 x N Blocks to
+rank b mod N (Blocks never exchange data, binary.rs:124-127, 167-171), and rank 0 adds a line
+with the whole-job rate: every rank's decoded bytes over the slowest rank's time.
+ZBRA_BENCH_BACKEND=gloo lets several ranks rehearse that on one GPU."""
 import argparse
 import json
 import os
@@ -85,27 +90,46 @@ def main():
     ap.add_argument("--reps", type=int, default=10)
     args = ap.parse_args()
     import torch
+    import torch.distributed as dist
 
-    from zbra_amd import workloads
-    dev = torch.device("cuda", 0)
+    from zbra_amd import sharding, workloads
+    rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    backend = os.environ.get("ZBRA_BENCH_BACKEND", "nccl")
+    dev = torch.device("cuda", local_rank if backend == "nccl" else local_rank % torch.cuda.device_count())
     torch.cuda.set_device(dev)
-    if 3 in args.config:
+    if world > 1:
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend=backend)
+    if 3 in args.config and world == 1:
         n = 1_000_000_000 >> args.scale_log2
         cols = workloads.mixed_width_column(n, 1 << 20, dev)
         print(json.dumps(run_batch(cols, "config 3: mixed widths, %d rows in 2^20-row arrays" % n, args.reps)), flush=True)
         del cols
         torch.cuda.empty_cache()
     if 4 in args.config:
-        blocks = max(1, 128 >> args.scale_log2)
+        blocks = max(1, 128 >> args.scale_log2)  # per GPU
         tags, ints = [], []
-        for b in range(blocks):
+        for b in sharding.shard_round_robin(blocks * world, world, rank):
             t, variants = workloads.enum_block(b, 1 << 22, dev)
             tags.append(t)
             for _, a, bcol in variants:
                 ints += [a, bcol]
         print(json.dumps(run_batch(tags, "config 4 (one GPU's 2^29 rows): enum tags -> u32, %d Blocks" % blocks, args.reps)), flush=True)
         print(json.dumps(run_batch(ints, "config 4: Int columns of the variants, %d arrays" % len(ints), args.reps)), flush=True)
-        print(json.dumps(run_batch(tags + ints, "config 4: tags + Int columns in one submission", args.reps)), flush=True)
+        if world > 1:
+            dist.barrier()
+        both = run_batch(tags + ints, "config 4: tags + Int columns in one submission", args.reps)
+        print(json.dumps(both), flush=True)
+        if world > 1:
+            ms, out_bytes = sharding.job_totals(both["decode_ms"], float(both["decoded_bytes"]), dev if backend == "nccl" else "cpu")
+            if rank == 0:
+                print(json.dumps({"case": "config 4, whole job: Block b on GPU b mod %d, no collective on the data path" % world,
+                                  "n_gpus": world, "blocks": blocks * world, "decode_ms_slowest_rank": round(ms, 4),
+                                  "decoded_GBps": round(out_bytes / ms / 1e6, 1)}), flush=True)
+            dist.destroy_process_group()
 
 
 if __name__ == "__main__":

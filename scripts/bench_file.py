@@ -4,7 +4,11 @@
 milliseconds, monotone, value: <= 12 bits), written by this package's batched writer.  Measures
 (i) the batched decode alone, image and values resident in HBM, and (ii) image in pageable host
 memory -> values in host memory through zbra_hip_file_index + zbra_hip_file_decode.  The scale
-(64 GB per file in the full configuration) is stated in the output."""
+(64 GB per file in the full configuration) is stated in the output.
+
+Under torch.distributed.run (one process per GPU) every rank writes and decodes its OWN file
+(file f on GPU f; files share nothing), and rank 0 adds a line with the whole-job rates.
+ZBRA_BENCH_BACKEND=gloo lets several ranks rehearse that on one GPU."""
 import argparse
 import ctypes as C
 import json
@@ -32,12 +36,23 @@ def main():
     ap.add_argument("--reps", type=int, default=3)
     args = ap.parse_args()
     import torch
+    import torch.distributed as dist
 
-    from zbra_amd import _lib, binary as zb, device
+    from zbra_amd import _lib, binary as zb, device, sharding
+    rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    backend = os.environ.get("ZBRA_BENCH_BACKEND", "nccl")
+    dev = torch.device("cuda", local_rank if backend == "nccl" else local_rank % torch.cuda.device_count())
+    torch.cuda.set_device(dev)  # also the device of the host-pointer calls of this thread
+    if world > 1:
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend=backend)
     n = 1 << args.rows_log2
     blocks = []
     with np.errstate(over="ignore"):
-        for b in range(args.blocks):
+        for b in range(rank * args.blocks, (rank + 1) * args.blocks):  # file `rank` holds these rows of the table
             i = np.arange(b * n, (b + 1) * n, dtype=np.uint64)
             entity = (1000 + (i // np.uint64(64)) % np.uint64(50000)).astype(np.int64)
             attribute = (sm(0x5EED0005, i) % np.uint64(200)).astype(np.int64)
@@ -53,7 +68,6 @@ def main():
     na = info.n_arrays
     out_bytes = 8 * int(info.total_values)
     # (i) device-resident: image in HBM, one batched submission
-    dev = torch.device("cuda", 0)
     d_img = torch.frombuffer(bytearray(img), dtype=torch.uint8).to(dev)
     outs = [torch.empty(arrays[k].count, dtype=torch.int64, device=dev) for k in range(na)]
     descs = device.make_descs([(d_img.data_ptr() + arrays[k].offset, arrays[k].len, arrays[k].count, outs[k].data_ptr(), _lib.ELEM_I64)
@@ -80,6 +94,8 @@ def main():
     statuses = (C.c_int * na)()
     buf = np.frombuffer(img, dtype=np.uint8)
     best = None
+    if world > 1:
+        dist.barrier()  # the ranks share the host's memory bandwidth and PCIe root complexes: run together
     for _ in range(args.reps + 1):
         t0 = time.perf_counter()
         st = _lib.lib.zbra_hip_file_decode(buf.ctypes.data_as(C.c_void_p), buf.size, arrays, na, ptrs, statuses)
@@ -94,7 +110,16 @@ def main():
         "kernel_only_ms": round(k_ms, 4), "kernel_only_decoded_GBps": round(out_bytes / k_ms / 1e6, 1),
         "kernel_only_algorithmic_GBps": round((enc_bytes + out_bytes) / k_ms / 1e6, 1),
         "hbm_frac": round((enc_bytes + out_bytes) / k_ms / 1e6 / 8000, 4),
-        "host_to_host_ms": round(best * 1e3, 2), "host_to_host_decoded_GBps": round(out_bytes / best / 1e9, 2)}))
+        "host_to_host_ms": round(best * 1e3, 2), "host_to_host_decoded_GBps": round(out_bytes / best / 1e9, 2)}), flush=True)
+    if world > 1:
+        red = dev if backend == "nccl" else "cpu"
+        k_all, bytes_all = sharding.job_totals(k_ms * 1e-3, float(out_bytes), red)
+        h_all, _ = sharding.job_totals(best, float(out_bytes), red)
+        if rank == 0:
+            print(json.dumps({"what": "whole job: file f on GPU f, no collective on the data path", "n_gpus": world,
+                              "kernel_only_decoded_GBps": round(bytes_all / k_all / 1e9, 1),
+                              "host_to_host_decoded_GBps": round(bytes_all / h_all / 1e9, 2)}), flush=True)
+        dist.destroy_process_group()
 
 
 if __name__ == "__main__":
