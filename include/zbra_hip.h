@@ -53,6 +53,9 @@ typedef enum zbra_status {
      * IntEncoding,BinaryEncoding}Tag / unexpected end of data   binary.rs:143-145, 268, 439, 500,
      * 526, 551, 570 */
     ZBRA_ERR_FORMAT = 7,
+    /* a row's enum tag is carried by no variant: SchemaError::UnsupportedType("enum tag N"),
+     * zbra-core/src/striped.rs:352-358 */
+    ZBRA_ERR_UNKNOWN_TAG = 8,
     ZBRA_ERR_HIP_BASE = 100   /* status - 100 = hipError_t */
 } zbra_status;
 
@@ -183,6 +186,19 @@ int zbra_hip_decode_dev(const uint8_t *d_data, size_t len, size_t count, void *d
  * stored: two reads of the packed bytes, one write of 8 bytes per value. */
 int zbra_hip_decode_offsets_dev(const uint8_t *d_data, size_t len, size_t count, uint64_t *d_offsets, zbra_dev_result *d_result,
                                 void *stream);
+
+/* The row loop of Column::from_values for an Enum column (zbra-core/src/striped.rs:340-387), from
+ * the tag column alone: for every row i, d_variant[i] = index of the FIRST variant whose tag equals
+ * d_tags[i] (striped.rs:349) and d_rank[i] = the row's position in that variant's column, i.e. the
+ * number of earlier rows of the same variant (variant_data[v].push, striped.rs:351); d_counts[v] =
+ * rows of variant v.  With these a payload column in HBM is scattered to / gathered from the
+ * variant columns by index.  variant_tags: n_variants (<= 32) tags in HOST memory (the schema).
+ * A tag that no variant carries: d_result->status = ZBRA_ERR_UNKNOWN_TAG, out_count = the first
+ * such row, midpoint = its tag (striped.rs:352-358), outputs undefined; else ZBRA_OK, out_count = n.
+ * Column::to_values (striped.rs:617-657) needs no counterpart: it reads variant column v at the
+ * row index itself (striped.rs:631-632). */
+int zbra_hip_enum_rows_dev(const uint32_t *d_tags, size_t n, const uint32_t *variant_tags, uint32_t n_variants,
+                           uint32_t *d_variant, uint64_t *d_rank, uint64_t *d_counts, zbra_dev_result *d_result, void *stream);
 
 /* The same for `nd` independent arrays in one submission (all arrays of a Block, or of many
  * Blocks: binary.rs:359-441 decodes them one after another).  `descs` is a HOST array whose

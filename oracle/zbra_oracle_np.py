@@ -147,3 +147,42 @@ def sm(seed: int, i):
         z = (z ^ (z >> _U64(30))) * _U64(0xBF58476D1CE4E5B9)
         z = (z ^ (z >> _U64(27))) * _U64(0x94D049BB133111EB)
         return z ^ (z >> _U64(31))
+
+
+def enum_rows(tags, variant_tags):
+    """The row loop of Column::from_values for an Enum column (zbra-core/src/striped.rs:344-359):
+    row i goes to the FIRST variant whose tag equals tags[i] (`position`, :349) and lands at the end
+    of that variant's list (:351), so its position there is the number of earlier rows of the same
+    variant.  Returns (status, variant[n] u32, rank[n] u64, counts[V] u64, first_bad_row); status 8
+    and first_bad_row = the row whose tag no variant carries (:352-358), where the reference stops."""
+    tags = np.asarray(tags).astype(np.uint32)
+    vt = [int(t) & 0xFFFFFFFF for t in variant_tags]
+    n = tags.size
+    variant = np.full(n, 0xFFFFFFFF, dtype=np.uint32)
+    for v in range(len(vt) - 1, -1, -1):          # later variants first, so the first match wins
+        variant[tags == np.uint32(vt[v])] = v
+    bad = np.flatnonzero(variant == 0xFFFFFFFF)
+    if bad.size:
+        return 8, variant, None, None, int(bad[0])
+    rank = np.zeros(n, dtype=np.uint64)
+    counts = np.zeros(len(vt), dtype=np.uint64)
+    for v in range(len(vt)):
+        m = variant == v
+        c = int(m.sum())
+        rank[m] = np.arange(c, dtype=np.uint64)
+        counts[v] = c
+    return 0, variant, rank, counts, -1
+
+
+def enum_rows_loop(tags, variant_tags):
+    """The same, statement by statement as the reference's loop (small inputs only)."""
+    lists = [[] for _ in variant_tags]
+    variant, rank = [], []
+    for i, tag in enumerate(tags):
+        pos = next((v for v, t in enumerate(variant_tags) if int(t) == int(tag)), None)   # striped.rs:349
+        if pos is None:
+            return 8, variant, rank, None, i                                              # :352-358
+        variant.append(pos)
+        rank.append(len(lists[pos]))
+        lists[pos].append(i)                                                              # :351
+    return 0, variant, rank, [len(x) for x in lists], -1

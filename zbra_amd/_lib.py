@@ -65,6 +65,7 @@ SIGNATURES = {
     "zbra_hip_bp64_unpack": (C.c_int, [_p, _sz, _sz, _p, _psz]),
     "zbra_hip_decode_dev": (C.c_int, [_p, _sz, _sz, _p, C.c_uint32, _p, _p]),
     "zbra_hip_decode_offsets_dev": (C.c_int, [_p, _sz, _sz, _p, _p, _p]),
+    "zbra_hip_enum_rows_dev": (C.c_int, [_p, _sz, _p, C.c_uint32, _p, _p, _p, _p, _p]),
     "zbra_hip_decode_batch_dev": (C.c_int, [C.POINTER(ArrayDesc), _sz, _p, _p]),
     "zbra_hip_encode_dev": (C.c_int, [_p, _sz, C.c_uint32, _p, _sz, _p, _p]),
     "zbra_hip_encode_batch_dev": (C.c_int, [C.POINTER(EncodeDesc), _sz, _p, _p]),
@@ -106,6 +107,7 @@ ERR_CAPACITY = 4
 ERR_INVALID_ARG = 5
 ERR_NO_DEVICE = 6
 ERR_FORMAT = 7
+ERR_UNKNOWN_TAG = 8
 ERR_HIP_BASE = 100
 ELEM_I64 = 0
 ELEM_U32 = 1

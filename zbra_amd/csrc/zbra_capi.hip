@@ -15,6 +15,7 @@
 #include "zbra_stages.hpp"
 #include "zbra_file.hpp"
 #include "zbra_offsets.hpp"
+#include "zbra_enum.hpp"
 
 namespace zbra {
 
@@ -658,6 +659,7 @@ const char *zbra_hip_strerror(int status) {
         case ZBRA_ERR_INVALID_ARG: return "Invalid argument";
         case ZBRA_ERR_NO_DEVICE: return "No usable HIP device";
         case ZBRA_ERR_FORMAT: return "Invalid .zbra image (magic number, tag or length)";
+        case ZBRA_ERR_UNKNOWN_TAG: return "enum tag carried by no variant";                // striped.rs:352-358
         default:
             if (status >= ZBRA_ERR_HIP_BASE) return hipGetErrorString((hipError_t)(status - ZBRA_ERR_HIP_BASE));
             return "unknown status";
@@ -834,6 +836,53 @@ int zbra_hip_decode_offsets_dev(const uint8_t *d_data, size_t len, size_t count,
     hipLaunchKernelGGL(offsets_write_kernel, dim3((unsigned)(ntiles ? ntiles : 1)), dim3(OFF_THREADS), 0, stream, plan, tile_sums, chunk_base,
                        d_offsets);
     int st = hip_status(hipGetLastError());
+    int st2 = ctx->release(s, stream);
+    return st != ZBRA_OK ? st : st2;
+}
+
+int zbra_hip_enum_rows_dev(const uint32_t *d_tags, size_t n, const uint32_t *variant_tags, uint32_t n_variants,
+                           uint32_t *d_variant, uint64_t *d_rank, uint64_t *d_counts, zbra_dev_result *d_result, void *stream_) {
+    if (n_variants > (uint32_t)ENUM_MAX_VARIANTS || (n_variants && (!variant_tags || !d_counts)) || n > MAX_COUNT ||
+        (n && (!d_tags || !d_variant || !d_rank)))
+        return ZBRA_ERR_INVALID_ARG;
+    DeviceCtx *ctx;
+    ZBRA_TRY(current_ctx(&ctx));
+    hipStream_t stream = (hipStream_t)stream_;
+    const uint64_t ntiles = ((uint64_t)n + ENUM_TILE - 1) / ENUM_TILE;
+    const uint64_t nchunks = (ntiles + SCAN_CHUNK - 1) / SCAN_CHUNK;
+    const size_t off_bad = ENUM_MAX_VARIANTS * sizeof(uint32_t), off_counts = 256;
+    Slot *s;
+    ZBRA_TRY(ctx->acquire(off_counts + (size_t)n_variants * (ntiles + nchunks) * sizeof(uint64_t), &s, 0, off_bad));
+    uint32_t *h_vt = (uint32_t *)s->host;
+    for (uint32_t v = 0; v < (uint32_t)ENUM_MAX_VARIANTS; v++) h_vt[v] = v < n_variants ? variant_tags[v] : 0;
+    const uint32_t *d_vt = (const uint32_t *)s->dev;
+    unsigned long long *d_bad = (unsigned long long *)((char *)s->dev + off_bad);
+    uint64_t *tile_counts = (uint64_t *)((char *)s->dev + off_counts);
+    uint64_t *chunk_base = tile_counts + (size_t)n_variants * ntiles;
+    int st = hip_status(hipMemcpyAsync(s->dev, s->host, off_bad, hipMemcpyHostToDevice, stream));
+    if (st == ZBRA_OK) st = hip_status(hipMemsetAsync(d_bad, 0xFF, sizeof(unsigned long long), stream));
+    if (st == ZBRA_OK && n_variants && ntiles == 0) st = hip_status(hipMemsetAsync(d_counts, 0, n_variants * sizeof(uint64_t), stream));
+    if (st == ZBRA_OK) {
+        if (ntiles) {
+            if (n_variants <= (uint32_t)ENUM_FEW) {
+                const uint64_t per_wg = (uint64_t)ENUM_WAVES * ENUM_COUNT_TILES;
+                hipLaunchKernelGGL(enum_counts_few_kernel, dim3((unsigned)((ntiles + per_wg - 1) / per_wg)), dim3(ENUM_THREADS), 0, stream, d_tags,
+                                   (uint64_t)n, d_vt, n_variants, ntiles, tile_counts, d_bad);
+            } else {
+                hipLaunchKernelGGL(enum_counts_kernel, dim3((unsigned)ntiles), dim3(ENUM_THREADS), 0, stream, d_tags, (uint64_t)n, d_vt, n_variants,
+                                   ntiles, tile_counts, d_bad);
+            }
+            if (n_variants) {
+                hipLaunchKernelGGL(enum_scan_chunks_kernel, dim3((unsigned)nchunks, n_variants), dim3(SCAN_CHUNK), 0, stream, ntiles, nchunks,
+                                   tile_counts, chunk_base);
+                hipLaunchKernelGGL(enum_scan_totals_kernel, dim3(n_variants), dim3(SCAN_CHUNK), 0, stream, nchunks, chunk_base, d_counts);
+            }
+            hipLaunchKernelGGL(enum_write_kernel, dim3((unsigned)ntiles), dim3(ENUM_THREADS), 0, stream, d_tags, (uint64_t)n, d_vt, n_variants,
+                               ntiles, nchunks, tile_counts, chunk_base, d_variant, d_rank);
+        }
+        hipLaunchKernelGGL(enum_report_kernel, dim3(1), dim3(64), 0, stream, d_tags, (uint64_t)n, d_bad, d_result);
+        st = hip_status(hipGetLastError());
+    }
     int st2 = ctx->release(s, stream);
     return st != ZBRA_OK ? st : st2;
 }

@@ -1,0 +1,276 @@
+// Rows of an Enum column dealt to their variants.
+//
+// Column::from_values (zbra-core/src/striped.rs:340-387) walks the rows once: it keeps every tag
+// (:347) and pushes the row's payload onto variant_data[v], v being the FIRST variant whose tag
+// equals the row's (`variants.iter().position(|v| v.tag == *tag)`, :349-351); a tag that no variant
+// carries ends the conversion with SchemaError::UnsupportedType("enum tag N") (:352-358).  What that
+// loop computes for row i is therefore a pair (v, position of the row in variant v's column), the
+// position being the number of earlier rows that went to the same variant.  These kernels produce
+// that pair for every row from the tag column alone, so that any payload column already in HBM can
+// be scattered to (or gathered from) its variant columns by index:
+//   variant[i] = v,  rank[i] = |{ j < i : variant[j] == v }|,  counts[v] = rows of variant v.
+// Three steps, like every stable partition: per-tile counts, a scan of the counts over the tiles
+// (per variant), and a second read of the tags that adds the pieces up.  HBM traffic: the tags
+// twice (4 B each), 4 + 8 B written per row.
+//
+// The other direction (Column::to_values, striped.rs:617-657) needs no kernel: the reference reads
+// variant column v at the ROW index (`values[row_idx]`, :631-632), not at the rank.
+#pragma once
+#include "zbra_encode.hpp"
+#include "zbra_offsets.hpp"
+
+namespace zbra {
+
+constexpr int ENUM_MAX_VARIANTS = 32;  // five ballots tell a lane which lanes hold its variant
+constexpr int ENUM_TILE = 2048;        // rows per tile
+constexpr int ENUM_THREADS = 256;
+constexpr int ENUM_WAVES = ENUM_THREADS / 64;
+constexpr int ENUM_PER = ENUM_TILE / ENUM_THREADS;  // rows per lane: a wave owns 512 consecutive rows, 64 per step
+constexpr uint32_t ENUM_LUT = 256;     // variant tags below this are looked up, not searched
+constexpr uint32_t ENUM_NONE = 0xFFFFFFFFu;
+constexpr int ENUM_FEW = 8;            // up to this many variants the counting pass keeps byte counters in two registers
+
+struct EnumShared {
+    uint32_t vtag[ENUM_MAX_VARIANTS];
+    uint8_t lut[ENUM_LUT];                             // tag -> variant, 0xFF = none
+    uint32_t wcnt[ENUM_WAVES][ENUM_MAX_VARIANTS];      // rows of each variant in each wave's 512 rows
+};
+
+// Fills vtag and lut; every lane of the workgroup calls it.  Ends with a barrier.
+__device__ __forceinline__ void enum_setup(EnumShared &sh, const uint32_t *__restrict__ variant_tags, uint32_t nv) {
+    for (uint32_t i = threadIdx.x; i < ENUM_LUT; i += ENUM_THREADS) sh.lut[i] = 0xFF;
+    if (threadIdx.x < (uint32_t)ENUM_MAX_VARIANTS) sh.vtag[threadIdx.x] = threadIdx.x < nv ? variant_tags[threadIdx.x] : 0;
+    for (uint32_t i = threadIdx.x; i < ENUM_WAVES * ENUM_MAX_VARIANTS; i += ENUM_THREADS) (&sh.wcnt[0][0])[i] = 0;
+    __syncthreads();
+    if (threadIdx.x == 0) {  // descending, so that the FIRST variant with a tag wins (striped.rs:349)
+        for (uint32_t v = nv; v-- > 0;)
+            if (sh.vtag[v] < ENUM_LUT) sh.lut[sh.vtag[v]] = (uint8_t)v;
+    }
+    __syncthreads();
+}
+
+__device__ __forceinline__ uint32_t enum_variant_of(const EnumShared &sh, uint32_t tag, uint32_t nv) {
+    if (tag < ENUM_LUT) {
+        const uint32_t v = sh.lut[tag];
+        return v == 0xFF ? ENUM_NONE : v;
+    }
+    for (uint32_t v = 0; v < nv; v++)
+        if (sh.vtag[v] == tag) return v;
+    return ENUM_NONE;
+}
+
+// The wave's 512 rows of the tile that starts at row r0, 64 consecutive rows per step: variant of
+// this lane's row of every step and its rank among the WAVE's rows of that variant so far.  A lane
+// finds the lanes that hold its variant with five ballots (one per bit of v); the lowest of them
+// adds the group's size to the wave's counter of that variant in LDS and hands the old value on.
+// first_bad = lowest row whose tag is no variant's (or ~0).
+__device__ __forceinline__ void enum_wave_rows(EnumShared &sh, const uint32_t *__restrict__ tags, uint64_t r0, uint64_t n, uint32_t nv,
+                                               uint32_t (&v)[ENUM_PER], uint32_t (&r)[ENUM_PER], uint64_t &first_bad) {
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    const uint64_t below = lane ? (~0ull >> (64 - lane)) : 0ull;
+    uint32_t t[ENUM_PER];
+#pragma unroll
+    for (int e = 0; e < ENUM_PER; e++) {
+        const uint64_t row = r0 + wave * (64u * ENUM_PER) + (uint32_t)e * 64u + lane;
+        t[e] = row < n ? tags[row] : 0u;
+    }
+#pragma unroll
+    for (int e = 0; e < ENUM_PER; e++) {
+        const uint64_t row = r0 + wave * (64u * ENUM_PER) + (uint32_t)e * 64u + lane;
+        const bool valid = row < n;
+        const uint32_t var = valid ? enum_variant_of(sh, t[e], nv) : ENUM_NONE;
+        if (valid && var == ENUM_NONE && row < first_bad) first_bad = row;
+        const bool counted = var != ENUM_NONE;
+        uint64_t peers = __ballot(counted);
+#pragma unroll
+        for (int b = 0; b < 5; b++) {
+            const uint64_t set = __ballot(counted && ((var >> b) & 1u));
+            peers &= ((var >> b) & 1u) ? set : ~set;
+        }
+        uint32_t base = 0;
+        if (counted) {
+            const uint32_t leader = (uint32_t)__builtin_ctzll(peers);
+            if (lane == leader) base = atomicAdd(&sh.wcnt[wave][var], (uint32_t)__popcll(peers));
+            base = __shfl(base, (int)leader);
+        }
+        v[e] = var;
+        r[e] = base + (uint32_t)__popcll(peers & below);
+    }
+}
+
+// 1. tile_counts[v * ntiles + t] = rows of variant v in tile t.
+__global__ __launch_bounds__(ENUM_THREADS) void enum_counts_kernel(const uint32_t *__restrict__ tags, uint64_t n,
+                                                                    const uint32_t *__restrict__ variant_tags, uint32_t nv, uint64_t ntiles,
+                                                                    uint64_t *__restrict__ tile_counts, unsigned long long *first_bad_row) {
+    __shared__ EnumShared sh;
+    enum_setup(sh, variant_tags, nv);
+    const uint64_t tile = blockIdx.x;
+    uint64_t bad = ~0ull;
+    uint32_t v[ENUM_PER], r[ENUM_PER];
+    enum_wave_rows(sh, tags, tile * ENUM_TILE, n, nv, v, r, bad);
+    bad = wave_min_u64(bad);
+    if ((threadIdx.x & 63u) == 0 && bad != ~0ull) atomicMin(first_bad_row, (unsigned long long)bad);
+    __syncthreads();
+    if (threadIdx.x < nv) {
+        uint32_t c = 0;
+#pragma unroll
+        for (int w = 0; w < ENUM_WAVES; w++) c += sh.wcnt[w][threadIdx.x];
+        tile_counts[(uint64_t)threadIdx.x * ntiles + tile] = c;
+    }
+}
+
+// 1b. The same for at most ENUM_FEW variants, which is what enums have: counting needs neither
+// the rows' order nor LDS.  A wave takes whole tiles on its own (no barrier, no set-up), a lane
+// takes 32 of a tile's rows with 16-byte loads and keeps one byte counter per variant in two
+// registers (at most 32 per byte); the wave adds the bytes up as 16-bit fields.  2^28 rows, 4
+// variants: 530 us for the general kernel above (131072 workgroups, each a chain of set-up and
+// load latencies for 8 KiB of tags), 300 us for this one.
+constexpr int ENUM_COUNT_TILES = 2;  // tiles per wave
+__device__ __forceinline__ void enum_count_tag(uint32_t tag, uint64_t row, const uint32_t (&vt)[ENUM_FEW], uint32_t live, uint32_t &lo,
+                                               uint32_t &hi, uint64_t &bad) {
+    bool any = false;
+#pragma unroll
+    for (int b = 0; b < 4; b++) {
+        const bool hit = ((live >> b) & 1u) && tag == vt[b];
+        lo += hit ? 1u << (8 * b) : 0u;
+        any = any || hit;
+    }
+    if (live >> 4) {  // uniform
+#pragma unroll
+        for (int b = 4; b < ENUM_FEW; b++) {
+            const bool hit = ((live >> b) & 1u) && tag == vt[b];
+            hi += hit ? 1u << (8 * (b - 4)) : 0u;
+            any = any || hit;
+        }
+    }
+    if (!any && row < bad) bad = row;
+}
+__device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+__global__ __launch_bounds__(ENUM_THREADS) void enum_counts_few_kernel(const uint32_t *__restrict__ tags, uint64_t n,
+                                                                        const uint32_t *__restrict__ variant_tags, uint32_t nv, uint64_t ntiles,
+                                                                        uint64_t *__restrict__ tile_counts, unsigned long long *first_bad_row) {
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    uint32_t vt[ENUM_FEW], live = 0;  // uniform; a variant whose tag an earlier one carries never gets a row (striped.rs:349)
+#pragma unroll
+    for (int b = 0; b < ENUM_FEW; b++) {
+        vt[b] = (uint32_t)b < nv ? variant_tags[b] : 0u;
+        bool first = (uint32_t)b < nv;
+        for (int a = 0; a < b; a++) first = first && vt[a] != vt[b];
+        live |= first ? 1u << b : 0u;
+    }
+    const bool aligned = ((uintptr_t)tags & 15u) == 0;  // tiles start at multiples of 8 KiB from `tags`
+    uint64_t bad = ~0ull;
+    for (int q = 0; q < ENUM_COUNT_TILES; q++) {
+        const uint64_t tile = ((uint64_t)blockIdx.x * ENUM_WAVES + wave) * ENUM_COUNT_TILES + q;
+        if (tile >= ntiles) break;  // uniform within the wave
+        const uint64_t r0 = tile * ENUM_TILE;
+        uint32_t lo = 0, hi = 0;
+        if (aligned && r0 + ENUM_TILE <= n) {
+            const ZBRA_GLOBAL u32x4 *src = (const ZBRA_GLOBAL u32x4 *)(gptr<uint32_t>(tags) + r0) + lane;
+            u32x4 x[ENUM_TILE / 256];
+#pragma unroll
+            for (int st = 0; st < ENUM_TILE / 256; st++) x[st] = __builtin_nontemporal_load(src + st * 64);
+#pragma unroll
+            for (int st = 0; st < ENUM_TILE / 256; st++) {
+                const uint64_t row = r0 + (uint32_t)st * 256u + lane * 4u;
+                enum_count_tag(x[st].x, row, vt, live, lo, hi, bad);
+                enum_count_tag(x[st].y, row + 1, vt, live, lo, hi, bad);
+                enum_count_tag(x[st].z, row + 2, vt, live, lo, hi, bad);
+                enum_count_tag(x[st].w, row + 3, vt, live, lo, hi, bad);
+            }
+        } else {
+            for (uint32_t st = 0; st < (uint32_t)ENUM_TILE / 64; st++) {
+                const uint64_t row = r0 + st * 64u + lane;
+                if (row < n) enum_count_tag(tags[row], row, vt, live, lo, hi, bad);
+            }
+        }
+        // bytes -> 16-bit fields (a wave's 2048 rows fit), summed over the lanes
+        const uint32_t f02 = wave_sum_u32(lo & 0x00FF00FFu), f13 = wave_sum_u32((lo >> 8) & 0x00FF00FFu);
+        const uint32_t f46 = wave_sum_u32(hi & 0x00FF00FFu), f57 = wave_sum_u32((hi >> 8) & 0x00FF00FFu);
+        const uint32_t c[ENUM_FEW] = {f02 & 0xFFFFu, f13 & 0xFFFFu, f02 >> 16, f13 >> 16, f46 & 0xFFFFu, f57 & 0xFFFFu, f46 >> 16, f57 >> 16};
+#pragma unroll
+        for (int b = 0; b < ENUM_FEW; b++)
+            if (lane == (uint32_t)b && (uint32_t)b < nv) tile_counts[(uint64_t)b * ntiles + tile] = c[b];
+    }
+    bad = wave_min_u64(bad);
+    if (lane == 0 && bad != ~0ull) atomicMin(first_bad_row, (unsigned long long)bad);
+}
+
+// 2. Exclusive scan of every variant's tile counts, two levels, as for the offsets: blockIdx.y is
+// the variant.  The second level also leaves counts[v].
+__global__ __launch_bounds__(SCAN_CHUNK) void enum_scan_chunks_kernel(uint64_t ntiles, uint64_t nchunks, uint64_t *__restrict__ tile_counts,
+                                                                       uint64_t *__restrict__ chunk_base) {
+    __shared__ uint64_t wtot[SCAN_CHUNK / 64];
+    uint64_t *col = tile_counts + (uint64_t)blockIdx.y * ntiles;
+    const uint64_t t = (uint64_t)blockIdx.x * SCAN_CHUNK + threadIdx.x;
+    const uint64_t x = t < ntiles ? col[t] : 0;
+    uint64_t total;
+    const uint64_t ex = block_exclusive_scan_1024(x, wtot, &total);
+    if (t < ntiles) col[t] = ex;
+    if (threadIdx.x == 0) chunk_base[(uint64_t)blockIdx.y * nchunks + blockIdx.x] = total;
+}
+__global__ __launch_bounds__(SCAN_CHUNK) void enum_scan_totals_kernel(uint64_t nchunks, uint64_t *__restrict__ chunk_base,
+                                                                       uint64_t *__restrict__ counts) {
+    __shared__ uint64_t wtot[SCAN_CHUNK / 64];
+    uint64_t *col = chunk_base + (uint64_t)blockIdx.x * nchunks;  // blockIdx.x is the variant
+    uint64_t carry = 0;
+    for (uint64_t c0 = 0; c0 < nchunks; c0 += SCAN_CHUNK) {  // uniform trip count
+        const uint64_t c = c0 + threadIdx.x;
+        const uint64_t x = c < nchunks ? col[c] : 0;
+        uint64_t total;
+        const uint64_t ex = block_exclusive_scan_1024(x, wtot, &total);
+        if (c < nchunks) col[c] = carry + ex;
+        carry += total;
+    }
+    if (threadIdx.x == 0) counts[blockIdx.x] = carry;
+}
+
+// 3. variant[i] and rank[i]: rows of the variant in earlier tiles + in earlier waves of the tile +
+// earlier in the wave.  A submission with an unknown tag is reported, its outputs are not defined.
+__global__ __launch_bounds__(ENUM_THREADS) void enum_write_kernel(const uint32_t *__restrict__ tags, uint64_t n,
+                                                                   const uint32_t *__restrict__ variant_tags, uint32_t nv, uint64_t ntiles,
+                                                                   uint64_t nchunks, const uint64_t *__restrict__ tile_counts,
+                                                                   const uint64_t *__restrict__ chunk_base, uint32_t *__restrict__ variant,
+                                                                   uint64_t *__restrict__ rank) {
+    __shared__ EnumShared sh;
+    __shared__ uint64_t start[ENUM_WAVES][ENUM_MAX_VARIANTS];  // rank of the wave's first row of each variant
+    enum_setup(sh, variant_tags, nv);
+    const uint64_t tile = blockIdx.x;
+    uint32_t v[ENUM_PER], r[ENUM_PER];
+    uint64_t bad = ~0ull;
+    enum_wave_rows(sh, tags, tile * ENUM_TILE, n, nv, v, r, bad);
+    __syncthreads();
+    if (threadIdx.x < nv) {
+        uint64_t run = chunk_base[(uint64_t)threadIdx.x * nchunks + tile / SCAN_CHUNK] + tile_counts[(uint64_t)threadIdx.x * ntiles + tile];
+#pragma unroll
+        for (int w = 0; w < ENUM_WAVES; w++) { start[w][threadIdx.x] = run; run += sh.wcnt[w][threadIdx.x]; }
+    }
+    __syncthreads();
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+#pragma unroll
+    for (int e = 0; e < ENUM_PER; e++) {
+        const uint64_t row = tile * ENUM_TILE + wave * (64u * ENUM_PER) + (uint32_t)e * 64u + lane;
+        if (row < n) {
+            __builtin_nontemporal_store(v[e], variant + row);
+            __builtin_nontemporal_store(v[e] != ENUM_NONE ? start[wave][v[e]] + r[e] : 0ull, rank + row);
+        }
+    }
+}
+
+// Status words: ZBRA_ERR_UNKNOWN_TAG with out_count = the first offending row and midpoint = its
+// tag, or ZBRA_OK with out_count = n.
+__global__ void enum_report_kernel(const uint32_t *__restrict__ tags, uint64_t n, const unsigned long long *first_bad_row,
+                                   zbra_dev_result *result) {
+    if (threadIdx.x != 0 || blockIdx.x != 0 || !result) return;
+    zbra_dev_result res;
+    res.status = ZBRA_OK; res.width = 0; res.out_count = n; res.midpoint = 0; res.packed_len = 0;
+    const unsigned long long bad = *first_bad_row;
+    if (bad != ~0ull) { res.status = ZBRA_ERR_UNKNOWN_TAG; res.out_count = bad; res.midpoint = (int64_t)tags[bad]; }
+    *result = res;
+}
+
+}  // namespace zbra

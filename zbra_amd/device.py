@@ -71,6 +71,24 @@ def decode_offsets_dev(encoded: torch.Tensor, count: int, offsets: torch.Tensor,
         _raise(st)
 
 
+def enum_rows_dev(tags: torch.Tensor, variant_tags, variant: torch.Tensor, rank: torch.Tensor, counts: torch.Tensor,
+                  result: torch.Tensor = None, stream=None):
+    """zbra_hip_enum_rows_dev: the row loop of Column::from_values for an Enum column
+    (striped.rs:340-387) from the tag column alone.  tags: int32/uint32 CUDA tensor; variant_tags:
+    host sequence of at most 32 tags (the schema's variants, in order); variant (4-byte), rank
+    (8-byte) CUDA tensors of len(tags); counts: 8-byte CUDA tensor of len(variant_tags)."""
+    import ctypes as C
+    n = tags.numel()
+    assert tags.is_cuda and tags.element_size() == 4 and variant.is_cuda and variant.element_size() == 4
+    assert rank.is_cuda and rank.element_size() == 8 and variant.numel() >= n and rank.numel() >= n
+    vt = (C.c_uint32 * max(1, len(variant_tags)))(*[int(t) & 0xFFFFFFFF for t in variant_tags])
+    assert counts.is_cuda and counts.element_size() == 8 and counts.numel() >= len(variant_tags)
+    st = lib.zbra_hip_enum_rows_dev(tags.data_ptr(), n, vt, len(variant_tags), variant.data_ptr(), rank.data_ptr(), counts.data_ptr(),
+                                    result.data_ptr() if result is not None else None, _stream_handle(stream))
+    if st:
+        _raise(st)
+
+
 def make_descs(items):
     """items: iterable of (data_ptr, len, count, out_ptr, kind) -> ctypes array of zbra_array_desc."""
     items = list(items)
