@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Encodes one device-resident column a few times (run it under rocprofv3 --kernel-trace --stats to
-see the per-kernel times).  Usage: enc_kernels.py narrow|wide|w40|full [rows_log2]"""
+see the per-kernel times).  Usage: enc_kernels.py narrow|wide|time|w40|full [rows_log2]"""
 import os
 import sys
 
@@ -18,6 +18,8 @@ if kind == "narrow":
     v = 1_700_000_000_000 + torch.randint(0, 4000, (n,), dtype=torch.int64, device=dev, generator=g)
 elif kind == "wide":
     v = torch.randint(-(1 << 24), 1 << 24, (n,), dtype=torch.int64, device=dev, generator=g)
+elif kind == "time":  # sorted: one timestamp a second
+    v = 1_640_995_200_000 + torch.arange(n, dtype=torch.int64, device=dev) * 1000
 elif kind == "w40":
     v = torch.randint(-(1 << 38), 1 << 38, (n,), dtype=torch.int64, device=dev, generator=g)
 else:
