@@ -176,7 +176,13 @@ __device__ __forceinline__ void packed_extract(const DecodePlan &p, uint64_t v0,
             const uint32_t j = it * TH * 2 + tid * 2;
             if (j < nv) {
                 const uint32_t b = base_bits + j * w;
-                const uint32_t z0 = extract_bits(lds, b, mask), z1 = extract_bits(lds, b + w, mask);
+                uint32_t z0, z1;
+                if (w <= 16u) {  // uniform: both values lie inside the 32 bits that start at b
+                    const uint32_t x = extract_bits(lds, b, 0xFFFFFFFFu);
+                    z0 = x & mask; z1 = (x >> w) & mask;
+                } else {
+                    z0 = extract_bits(lds, b, mask); z1 = extract_bits(lds, b + w, mask);
+                }
                 const int64_t o0 = plain ? (int64_t)z0 : mid + (int64_t)zigzag_decode32(z0);
                 const int64_t o1 = plain ? (int64_t)z1 : mid + (int64_t)zigzag_decode32(z1);
                 store_pair_i64<NT>(out, j, nv, o0, o1);
@@ -192,10 +198,18 @@ __device__ __forceinline__ void packed_extract(const DecodePlan &p, uint64_t v0,
             if (j < nv) {
                 const uint32_t b = base_bits + j * w;
                 u32x4 v;
-                v.x = mid + (uint32_t)zigzag_decode32(extract_bits(lds, b, mask));
-                v.y = mid + (uint32_t)zigzag_decode32(extract_bits(lds, b + w, mask));
-                v.z = mid + (uint32_t)zigzag_decode32(extract_bits(lds, b + 2 * w, mask));
-                v.w = mid + (uint32_t)zigzag_decode32(extract_bits(lds, b + 3 * w, mask));
+                if (w <= 8u) {  // uniform: the lane's four values lie inside the 32 bits that start at b
+                    const uint32_t x = extract_bits(lds, b, 0xFFFFFFFFu);
+                    v.x = mid + (uint32_t)zigzag_decode32(x & mask);
+                    v.y = mid + (uint32_t)zigzag_decode32((x >> w) & mask);
+                    v.z = mid + (uint32_t)zigzag_decode32((x >> (2 * w)) & mask);
+                    v.w = mid + (uint32_t)zigzag_decode32((x >> (3 * w)) & mask);
+                } else {
+                    v.x = mid + (uint32_t)zigzag_decode32(extract_bits(lds, b, mask));
+                    v.y = mid + (uint32_t)zigzag_decode32(extract_bits(lds, b + w, mask));
+                    v.z = mid + (uint32_t)zigzag_decode32(extract_bits(lds, b + 2 * w, mask));
+                    v.w = mid + (uint32_t)zigzag_decode32(extract_bits(lds, b + 3 * w, mask));
+                }
                 if (j + 3 < nv) {
                     st_stream<NT>(v, (ZBRA_GLOBAL u32x4 *)(out + j));
                 } else {
