@@ -175,11 +175,11 @@ def main():
     encode = None
     if not args.no_encode_bench:
         enc_buf = torch.empty(cap, dtype=torch.uint8, device=dev)
-        for _ in range(2):
+        for _ in range(5):
             device.encode_dev(values, enc_buf, res)
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        reps = 10
+        reps = 30
         e0.record()
         for _ in range(reps):
             device.encode_dev(values, enc_buf, res)
