@@ -282,8 +282,8 @@ static int encode_batch_dev(DeviceCtx *ctx, const EncodeItem *items, size_t nd, 
         // arrays of up to SAMPLE values are sorted whole by the sample kernel and need no pass
         if (items[i].n && items[i].kind != KIND_U64_PLAIN && (!bracket || items[i].n > (uint64_t)SAMPLE)) {
             h_list[n_list++] = (uint32_t)i;
-            // what the select of an array reads is never longer than the array
-            if (items[i].n > small_max) {
+            // only longer arrays can be left to the pass-per-launch kernels (enc_select_small_kernel)
+            if (items[i].n > (uint64_t)CAND_DIV * small_max) {
                 n_big++;
                 if (items[i].kind != ZBRA_ELEM_U32) big_passes = (uint32_t)MAX_PASSES;
             }

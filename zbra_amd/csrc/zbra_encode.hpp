@@ -824,7 +824,11 @@ __global__ __launch_bounds__(THREADS) void enc_select_small_kernel(EncodeJob *__
     const uint32_t passes = job.passes, mode = job.mode;
     if (passes == 0 || mode == SEL_DONE) return;
     const uint64_t src_n = mode == SEL_FULL ? job.n : mode == SEL_BRACKET_COMPACT ? job.inb : 0;
-    if (src_n > small_max) {  // too long for one workgroup: onto the list of the pass-per-launch kernels
+    // A candidate list holds at most n / CAND_DIV values, so an array of up to CAND_DIV * small_max
+    // values can only exceed small_max by reading all its values (no list, or a bracket that
+    // missed); those stay here too, which lets the host skip the pass-per-launch kernels for a
+    // submission without longer arrays (a 2^16-value array: 7 launches instead of 19).
+    if (src_n > small_max && job.n > (uint64_t)CAND_DIV * small_max) {  // too long for one workgroup
         if (threadIdx.x == 0) pending[1 + atomicAdd(&pending[0], 1u)] = a;
         return;
     }
