@@ -311,7 +311,7 @@ static int encode_batch_dev(DeviceCtx *ctx, const EncodeItem *items, size_t nd, 
                                bracket ? 1u : 0u);
             // arrays outside the list (sorted whole by the sample kernel, or plain u64) need
             // neither the bracket pass nor any select pass: a submission of short arrays is five
-            // launches, not eighteen
+            // launches, not nineteen
             if (n_list)
                 hipLaunchKernelGGL(enc_bracket_kernel, dim3(gs), dim3(THREADS), 0, stream, d_jobs, d_ts, (uint32_t)nd, ntiles, d_hist);
         }
