@@ -8,11 +8,18 @@ device by this library, then decoded K times.  A step = one decode of the whole 
 column (rows [rank*2^28, (rank+1)*2^28) of the same generator): weak scaling, no collectives on
 the data path.
 
+`python bench.py --gpus N` with N > 1 and no WORLD_SIZE in the environment starts the N ranks
+itself (one child process per GPU, before anything in this process touches the GPU) and relays
+rank 0's line; under `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N` the
+ranks already exist and each process is one of them.
+
 Prints ONE JSON line on rank 0.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -35,18 +42,68 @@ def parse_args():
     return ap.parse_args()
 
 
+def spawn_ranks(n: int, argv, child=None, env=None, timeout_s: float = 3000.0) -> int:
+    """Starts n child processes, one per rank (RANK = LOCAL_RANK = 0..n-1, WORLD_SIZE = n, rendezvous
+    on 127.0.0.1), lets rank 0 write to this process's stdout, waits for all of them and returns 0
+    only if every one exited with 0.  When one fails the others are terminated (by PID) and its exit
+    code is returned.  Must be called before this process initialises the GPU: the children are new
+    processes, nothing is exec'ed over this one."""
+    child = list(child) if child is not None else [sys.executable, os.path.abspath(__file__)]
+    base = dict(os.environ if env is None else env)
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    base.update(WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    procs = []
+    for r in range(n):
+        e = dict(base, RANK=str(r), LOCAL_RANK=str(r))
+        # ranks other than 0 print nothing to stdout (rank 0 owns the ONE JSON line); stderr is shared
+        procs.append(subprocess.Popen(child + list(argv), env=e, stdout=None if r == 0 else subprocess.DEVNULL))
+    deadline = time.monotonic() + timeout_s
+    rc, left = 0, set(range(n))
+    while left and rc == 0:
+        for r in sorted(left):
+            code = procs[r].poll()
+            if code is None:
+                continue
+            left.discard(r)
+            if code != 0:
+                rc = code if code > 0 else 128 - code
+                print(f"bench.py: rank {r} exited with {code}", file=sys.stderr, flush=True)
+                break
+        if time.monotonic() > deadline:
+            rc = 124
+            print("bench.py: ranks timed out", file=sys.stderr, flush=True)
+        if left and rc == 0:
+            time.sleep(0.05)
+    for r in left:  # only after a failure: end the ranks that would wait for the failed one forever
+        procs[r].terminate()
+    for r in left:
+        try:
+            procs[r].wait(timeout=10)
+        except subprocess.TimeoutExpired:
+            procs[r].kill()
+            procs[r].wait()
+    return rc
+
+
 def pmc_traffic(rows_log2: int):
-    """HBM bytes per decode launch from the PMC counters.  rocprofv3 cannot run inside the timed
-    process, so the figure comes from profiles/: separate --pmc FETCH_SIZE / --pmc WRITE_SIZE
-    passes over this same command (with the gfx950 FETCH_SIZE x2 correction applied there)."""
+    """HBM bytes per decode launch from the PMC counters, and where the figure comes from.
+    rocprofv3 cannot run inside the timed process, so it is read from the newest
+    profiles/*_pmc_traffic.json: separate --pmc FETCH_SIZE / --pmc WRITE_SIZE passes over this
+    same command (with the gfx950 FETCH_SIZE x2 correction applied there), not this run."""
     if rows_log2 != 28:
-        return None
+        return None, None
     try:
         names = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_pmc_traffic.json"))
-        with open(os.path.join(ROOT, "profiles", names[-1])) as f:
-            return int(json.load(f)["hbm_bytes_per_launch"]["total"])
+        path = os.path.join(ROOT, "profiles", names[-1])
+        with open(path) as f:
+            doc = json.load(f)
+        src = {"file": "profiles/" + names[-1], "collected": doc.get("collected"),
+               "note": "separate rocprofv3 --pmc passes over this command, not this run"}
+        return int(doc["hbm_bytes_per_launch"]["total"]), src
     except Exception:
-        return None
+        return None, None
 
 
 def cpu_baseline(n_sample: int, budget_s: float):
@@ -98,6 +155,15 @@ def cpu_baseline(n_sample: int, budget_s: float):
 
 def main():
     args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # the parent only launches: torch is not imported and HIP is not touched in this process
+        sys.exit(spawn_ranks(args.gpus, sys.argv[1:]))
+    if os.environ.get("ZBRA_BENCH_DRY_RANK") == "1":
+        # launcher rehearsal on a machine without a GPU: say where this rank sits in the job and stop
+        rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+        print(json.dumps({"dry": True, "rank": rank, "n_gpus": world,
+                          "config": {"partitioning": f"columns x{world}, no collectives"}}), flush=True)
+        return
     import torch
     import torch.distributed as dist
 
@@ -192,6 +258,7 @@ def main():
         del enc_buf
 
     if rank == 0:
+        traffic, traffic_src = pmc_traffic(args.rows_log2)
         value = decoded_bytes / elapsed / 1e9
         algo_bytes = enc_len + 8.0 * n  # per launch: encoded bytes read + int64 written
         achieved = algo_bytes / (kernel_ms * 1e-3) / 1e9
@@ -212,7 +279,7 @@ def main():
                                    "bit width 12, decode of device-resident bytes",
                        "rows_per_gpu": n, "bit_width": 12, "encoded_bytes": enc_len, "partitioning": f"columns x{world}, no collectives"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": pmc_traffic(args.rows_log2),
+                         "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic, "traffic_source": traffic_src,
                          "kernel": "decode_tiles_kernel", "kernel_ms": round(kernel_ms, 4),
                          "algorithmic_bytes_per_launch": int(algo_bytes)},
         }

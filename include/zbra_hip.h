@@ -142,6 +142,13 @@ int zbra_hip_init(void);
 /* 13 + 8*n for n > 0, else 0: capacity that compress_int_array's result never exceeds. */
 size_t zbra_hip_encode_bound(size_t n);
 
+/* Length of the Vec that decompress_int_array(data, count) returns, and its status, from the header
+ * alone (compression.rs:296-321, bp64_unpack :182-189): 0 values for empty data and for
+ * packed_len == 0 whatever `count` says, else `count`; the same status a decode call gives.  Pure
+ * host code on HOST bytes, no device needed.  The batched calls below write nothing to an output
+ * whose array yields 0 values: callers size the result with this. */
+int zbra_hip_decoded_count(const uint8_t *data, size_t len, size_t count, size_t *out_count);
+
 /* ---- full pipeline, host pointers --------------------------------------------------------- */
 
 /* compress_int_array(values: &[i64]) -> Vec<u8>                      compression.rs:271-292 */

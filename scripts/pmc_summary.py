@@ -3,6 +3,7 @@
 <tag>_pmc_traffic.json: HBM bytes per launch of the decode tile kernel, beside the algorithmic
 bytes.  Usage: scripts/pmc_summary.py <dir> <tag>"""
 import csv
+import datetime
 import json
 import re
 import sys
@@ -39,6 +40,7 @@ def table(per):
 
 
 json.dump({
+    "collected": datetime.datetime.now(datetime.timezone.utc).strftime("%Y-%m-%d"),
     "command": "rocprofv3 --pmc FETCH_SIZE (then, in a run of its own, --pmc WRITE_SIZE) --output-format csv -- "
                "python3 bench.py --steps 5 --warmup 2 --cpu-seconds 0",
     "kernel": dec,

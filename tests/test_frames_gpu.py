@@ -79,9 +79,12 @@ def test_host_frames_capacity(env):
     statuses = (C.c_int * len(vs))()
     st = L.lib.zbra_hip_encode_frames(descs, len(vs), out.ctypes.data_as(C.c_void_p), cap, offsets, statuses)
     assert st == L.ERR_CAPACITY
-    assert list(statuses)[:3] == [0, L.ERR_CAPACITY, L.ERR_CAPACITY]
+    # frames are laid out in order: everything after the first frame that does not fit fails too
+    # (even the 8-byte empty frame) and is reported as the empty range at the end of what was written
+    assert list(statuses) == [0, L.ERR_CAPACITY, L.ERR_CAPACITY, L.ERR_CAPACITY]
+    assert list(offsets) == [0] + [int(offs[1])] * 4
     assert out[: offs[1]].tobytes() == want[: offs[1]]
-    assert (out[cap:] == 0xAB).all(), "wrote past cap"
+    assert (out[offs[1]:] == 0xAB).all(), "bytes of frames that were not laid out reached the caller"
     # exact capacity is enough
     st = L.lib.zbra_hip_encode_frames(descs, len(vs), out.ctypes.data_as(C.c_void_p), len(want), offsets, statuses)
     assert st == 0 and list(offsets) == list(offs) and out[: len(want)].tobytes() == want
@@ -122,6 +125,14 @@ def test_host_batch_decode_of_scattered_arrays(env):
         assert g.dtype == a.dtype and np.array_equal(g, a)
     # count larger than what was encoded for an empty array: empty result, not an error
     assert zc.read_int_arrays_compressed([(b"", 7, np.int64)])[0].size == 0
+    # a 12-byte E with packed_len == 0 yields an empty Vec whatever count says (compression.rs:182-184
+    # through :318-321), also in the middle of a batch and for u32 outputs
+    hollow = b"\x05" + b"\0" * 11
+    assert oc.decompress_int_array(hollow, 9)[1].size == 0
+    mixed = zc.read_int_arrays_compressed([items[0], (hollow, 9, np.int64), (hollow + b"\xee\xee", 5, np.uint32), items[1]])
+    assert [m.size for m in mixed] == [arrs[0].size, 0, 0, arrs[1].size]
+    assert np.array_equal(mixed[0], arrs[0]) and np.array_equal(mixed[3], arrs[1])
+    assert zc.decoded_count(hollow, 9) == 0 and zc.decoded_count(items[0][0], arrs[0].size) == arrs[0].size
     bad = list(items)
     k = next(i for i, it in enumerate(items) if len(it[0]) > 20)
     e = bytearray(items[k][0])

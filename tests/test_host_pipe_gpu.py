@@ -114,3 +114,34 @@ def test_host_calls_from_threads(env):
     for t in ts:
         t.join()
     assert not errs, errs
+
+
+def test_short_raw_payload_first_call_in_fresh_process(tmp_path):
+    """A raw array (width byte >= 32) whose payload ends before later 64-MiB pieces begin, decoded as
+    the FIRST call of a process: the input buffer on the device is then only as large as the few
+    bytes of E, and pieces that start past the payload must not read outside it.  Every value past
+    the payload is 0 -> midpoint (compression.rs:196-205)."""
+    import os
+    import subprocess
+    import sys
+    from conftest import ROOT
+    script = tmp_path / "fresh.py"
+    script.write_text(
+        "import struct, sys\n"
+        "import numpy as np\n"
+        f"sys.path.insert(0, {ROOT!r})\n"
+        "from oracle import zbra_oracle_c as oc\n"
+        "from zbra_amd import compression as zc\n"
+        "n = (1 << 24) + 3\n"
+        "e = struct.pack('<qIB', 41, 9, 40) + bytes(range(1, 9))\n"
+        "st, want = oc.decompress_int_array(e, n)\n"
+        "assert st == 0 and want.shape == (n,)\n"
+        "got = zc.decompress_int_array(e, n)\n"
+        "assert np.array_equal(got, want)\n"
+        "got32 = zc.decompress_u32_array(e, 2 * n)\n"
+        "st, want = oc.decompress_int_array(e, 2 * n)\n"
+        "assert np.array_equal(got32, want.astype(np.uint32))\n"
+        "print('fresh ok')\n")
+    out = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, timeout=300,
+                         env=dict(os.environ))
+    assert out.returncode == 0 and "fresh ok" in out.stdout, out.stderr[-2000:]

@@ -53,6 +53,7 @@ SIGNATURES = {
     "zbra_hip_set_device": (C.c_int, [C.c_int]),
     "zbra_hip_init": (C.c_int, []),
     "zbra_hip_encode_bound": (_sz, [_sz]),
+    "zbra_hip_decoded_count": (C.c_int, [_p, _sz, _sz, _psz]),
     "zbra_hip_encode_i64": (C.c_int, [_p, _sz, _p, _sz, _psz]),
     "zbra_hip_encode_u32": (C.c_int, [_p, _sz, _p, _sz, _psz]),
     "zbra_hip_decode_i64": (C.c_int, [_p, _sz, _sz, _p, _psz]),

@@ -362,10 +362,11 @@ def file_decode(image, info, arrays):
     st = lib.zbra_hip_file_decode(buf.ctypes.data_as(C.c_void_p), buf.size, arrays, n, ptrs, statuses)
     if st:
         _gpu._raise(st)
-    # decompress_int_array returns an empty Vec for empty data whatever count says
+    # decompress_int_array returns an empty Vec for empty data and for packed_len == 0 whatever
+    # count says (compression.rs:296-298, :182-184): the device wrote nothing there
     for i in range(n):
-        if arrays[i].len == 0:
-            outs[i] = outs[i][:0]
+        a = arrays[i]
+        outs[i] = outs[i][:_gpu.decoded_count(buf[a.offset:a.offset + a.len], a.count)]
     return outs
 
 

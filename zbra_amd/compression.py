@@ -126,6 +126,17 @@ def compress_int_array(values) -> bytes:
     return out[: n.value].tobytes()
 
 
+def decoded_count(data, count: int) -> int:
+    """Length of the Vec decompress_int_array(data, count) returns (zbra_hip_decoded_count); raises
+    what the decode would raise.  Host only."""
+    d = _bytes_arr(data)
+    n = C.c_size_t(0)
+    st = lib.zbra_hip_decoded_count(_ptr(d), d.size, count, C.byref(n))
+    if st:
+        _raise(st)
+    return n.value
+
+
 def decompress_int_array(data, count: int):
     """decompress_int_array(data: &[u8], count) -> Result<Vec<i64>>     compression.rs:295-330"""
     d = _bytes_arr(data)
@@ -208,5 +219,6 @@ def read_int_arrays_compressed(arrays):
     st = lib.zbra_hip_decode_batch(descs, n, statuses)
     if st:
         _raise(st)
-    # decompress_int_array returns an empty Vec for empty data whatever count says
-    return [o[:0] if k.size == 0 else o for o, k in zip(outs, keep)]
+    # decompress_int_array returns an empty Vec for empty data and for packed_len == 0 whatever
+    # count says (compression.rs:296-298, :182-184): the device wrote nothing there
+    return [o[:decoded_count(k, o.size)] for o, k in zip(outs, keep)]

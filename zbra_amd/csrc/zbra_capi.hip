@@ -414,9 +414,13 @@ static int decode_host_pieces(DeviceCtx *ctx, const uint8_t *data, size_t used, 
         const uint64_t v0 = (uint64_t)c * per, nv = count - v0 < per ? count - v0 : per;
         const uint64_t o = w == 0 ? 0 : w < 32 ? v0 * w / 8 : v0 * 8;
         DecodePlan p;
-        p.payload = (const uint8_t *)ctx->dev_in.ptr + 13 + o;
+        // A raw piece that starts past the end of a short payload has no byte to read: its pointer
+        // stays at the last byte that was uploaded (dev_in holds used + 16 bytes, no more), so the
+        // aligned 16-byte chunk a lane may touch before it zeroes the value lies inside dev_in.
+        const uint64_t oc = o < avail ? o : avail;
+        p.payload = (const uint8_t *)ctx->dev_in.ptr + 13 + oc;
         p.out = (char *)ctx->dev_out.ptr + v0 * esz;
-        p.count = nv; p.midpoint = mid; p.avail = o < avail ? avail - o : 0; p.width = w; p.kind = kind;
+        p.count = nv; p.midpoint = mid; p.avail = avail - oc; p.width = w; p.kind = kind;
         std::memcpy((char *)s->host + c * 128, &p, sizeof(p));
         const uint64_t ts[2] = {0, decode_tiles_of(nv, kind)};
         std::memcpy((char *)s->host + c * 128 + 64, ts, sizeof(ts));
@@ -683,6 +687,11 @@ int zbra_hip_init(void) {
 
 size_t zbra_hip_encode_bound(size_t n) { return n == 0 ? 0 : 13 + 8 * n; }
 
+int zbra_hip_decoded_count(const uint8_t *data, size_t len, size_t count, size_t *out_count) {
+    if (!out_count || (len && !data) || count > MAX_COUNT) return ZBRA_ERR_INVALID_ARG;
+    return host_check_decode(data, len, count, out_count);
+}
+
 int zbra_hip_encode_i64(const int64_t *values, size_t n, uint8_t *out, size_t cap, size_t *out_len) {
     return encode_host(values, n, ZBRA_ELEM_I64, out, cap, out_len);
 }
@@ -942,7 +951,17 @@ int zbra_hip_encode_frames(const zbra_encode_desc *descs, size_t nd, uint8_t *ou
     std::vector<HostPipe::Segment> segs;
     size_t written = 0;
     int first_err = ZBRA_OK;
+    bool full = false;  // a frame did not fit
     for (size_t r0 = 0; r0 < nd;) {
+        if (full) {
+            // frames are laid out in order: after the first that did not fit nothing more is
+            // written, and every later array is reported as an empty range at the end
+            for (size_t i = r0; i < nd; i++) {
+                offsets[i + 1] = written;
+                if (statuses) statuses[i] = ZBRA_ERR_CAPACITY;
+            }
+            break;
+        }
         size_t r1 = r0, total_in = 0, bound = 0;
         while (r1 < nd && r1 - r0 < ROUND_ARRAYS && (r1 == r0 || total_in + in_bytes(r1) <= ROUND_IN)) {
             total_in += in_bytes(r1);
@@ -981,6 +1000,7 @@ int zbra_hip_encode_frames(const zbra_encode_desc *descs, size_t nd, uint8_t *ou
             offsets[r0 + i] = written + h_off[i];
             if (statuses) statuses[r0 + i] = (int)h_res[i].status;
             if (h_res[i].status != ZBRA_OK && first_err == ZBRA_OK) first_err = (int)h_res[i].status;
+            if (h_res[i].status == ZBRA_ERR_CAPACITY) full = true;
         }
         written += laid_out;
         offsets[r1] = written;

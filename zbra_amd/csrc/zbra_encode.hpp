@@ -946,14 +946,16 @@ __global__ __launch_bounds__(THREADS) void enc_or_kernel(EncodeJob *__restrict__
 // back-to-back frames `u32 count | u32 clen | E` in one buffer.  Sizes are known once the widths
 // are, so one workgroup scans them, points every job's `out` at its place behind its frame header,
 // writes the 8 header bytes and the offsets (offsets[nd] = total).  A frame that would pass `cap`
-// gets capacity 0, which the finalize kernel turns into ZBRA_ERR_CAPACITY; offsets then stop
-// growing, so offsets[nd] is the number of bytes actually laid out.
+// gets capacity 0, which the finalize kernel turns into ZBRA_ERR_CAPACITY.  Frame ends only grow,
+// so every frame after the first that does not fit fails too: all of them are reported as the
+// empty range [stop, stop) at the end of the last frame that fits, and offsets[nd] = stop is the
+// number of bytes actually laid out.
 __global__ __launch_bounds__(256) void enc_frame_layout_kernel(EncodeJob *__restrict__ jobs, uint32_t nd, uint8_t *out_base,
                                                                uint64_t cap, uint64_t *__restrict__ offsets) {
     __shared__ uint64_t scan[256];
-    __shared__ uint64_t carry;
+    __shared__ uint64_t carry, stop;
     const uint32_t tid = threadIdx.x;
-    if (tid == 0) carry = 0;
+    if (tid == 0) { carry = 0; stop = ~0ull; }
     __syncthreads();
     for (uint32_t a0 = 0; a0 < nd; a0 += 256) {
         const uint32_t a = a0 + tid;
@@ -979,8 +981,9 @@ __global__ __launch_bounds__(256) void enc_frame_layout_kernel(EncodeJob *__rest
             EncodeJob &j = jobs[a];
             const uint64_t end = base + scan[tid], off = end - len;
             const bool fits = end <= cap;
-            offsets[a] = off < cap ? off : cap;
-            if (a == nd - 1) offsets[nd] = fits ? end : (off < cap ? off : cap);
+            offsets[a] = off;
+            if (a == nd - 1) offsets[nd] = end;
+            if (!fits && off <= cap) stop = off;  // the first frame that does not fit: the one that starts inside cap
             if (fits) {
                 uint8_t *f = out_base + off;
                 const uint32_t cnt = (uint32_t)j.n, clen = (uint32_t)e_len;  // `as u32`, binary.rs:640-642
@@ -996,6 +999,10 @@ __global__ __launch_bounds__(256) void enc_frame_layout_kernel(EncodeJob *__rest
         if (tid == 255) carry = base + scan[255];
         __syncthreads();
     }
+    const uint64_t s = stop;
+    if (s != ~0ull)
+        for (uint32_t a = tid; a <= nd; a += 256)
+            if (offsets[a] > s) offsets[a] = s;
 }
 
 // Writes midpoint | packed_len | width (compression.rs:131, 287-288) and the result words.
