@@ -54,7 +54,7 @@ struct EncodeJob {
     uint32_t need_or;
     // bracket select
     uint32_t mode;       // SelectMode
-    uint32_t reserved0;
+    uint32_t frame_dropped;  // framed output: the array's frame did not fit (set by the layout kernel)
     uint64_t lo_b, hi_b; // bracket, inclusive, in biased (v ^ SIGN) space
     uint64_t below, inb; // exact counts of values below / inside the bracket (summed by the setup kernel)
     uint64_t key_base;   // keys of the radix select are (v ^ SIGN) - key_base
@@ -993,6 +993,7 @@ __global__ __launch_bounds__(256) void enc_frame_layout_kernel(EncodeJob *__rest
             } else {
                 j.out = nullptr;
                 j.cap = 0;
+                j.frame_dropped = 1;  // an empty array has no E whose capacity could fail: its 8-byte frame did
             }
         }
         __syncthreads();
@@ -1014,6 +1015,7 @@ __global__ void enc_finalize_kernel(EncodeJob *__restrict__ jobs, uint32_t nd, z
     r.status = ZBRA_OK; r.width = 0; r.out_count = 0; r.midpoint = 0; r.packed_len = 0;
     if (j.n == 0) {                       // compression.rs:272-274: empty in, empty out
         j.width = WIDTH_SKIP;
+        if (j.frame_dropped) r.status = ZBRA_ERR_CAPACITY;
     } else {
         if (j.need_or) j.width = width_of(j.or_bits);
         const uint32_t w = j.width;
