@@ -56,6 +56,8 @@ typedef enum zbra_status {
     /* a row's enum tag is carried by no variant: SchemaError::UnsupportedType("enum tag N"),
      * zbra-core/src/striped.rs:352-358 */
     ZBRA_ERR_UNKNOWN_TAG = 8,
+    /* zbra_hip_decode_batch_dev_noalloc: more arrays or more tiles than its fixed scratch holds */
+    ZBRA_ERR_NOALLOC_LIMIT = 9,
     ZBRA_ERR_HIP_BASE = 100   /* status - 100 = hipError_t */
 } zbra_status;
 
@@ -211,6 +213,26 @@ int zbra_hip_enum_rows_dev(const uint32_t *d_tags, size_t n, const uint32_t *var
  * Blocks: binary.rs:359-441 decodes them one after another).  `descs` is a HOST array whose
  * data/out members are DEVICE pointers; d_results (may be NULL) receives nd entries. */
 int zbra_hip_decode_batch_dev(const zbra_array_desc *descs, size_t nd, zbra_dev_result *d_results, void *stream);
+
+/* zbra_hip_decode_batch_dev for callers that cannot allocate: code under HIP graph capture, tight
+ * serving loops, harnesses that forbid hipMalloc.  It has no counterpart in the reference.  Same
+ * arguments, same results and same kernels as zbra_hip_decode_batch_dev, but the decode plans, the
+ * tiles-per-array scan and the tile -> array table live in a fixed array of device memory inside
+ * the library (about 4.2 MiB on every GPU the library runs on, held until the process ends), and
+ * the descriptors travel in kernel arguments: the call is kernel launches only, no hipMalloc, no
+ * hipFree, no copy, no pinned staging.
+ * Limits: nd <= ZBRA_HIP_NOALLOC_MAX_ARRAYS, and the submission's tiles, sum over the arrays of
+ * ceil(count / 2048) for i64 outputs and ceil(count / 4096) for u32 outputs, at most
+ * ZBRA_HIP_NOALLOC_MAX_TILES (2^31 int64 values in full tiles); beyond either the call does nothing
+ * and returns ZBRA_ERR_NOALLOC_LIMIT.
+ * Every call on a GPU uses that GPU's one array: calls whose work may overlap on one GPU (different
+ * streams, different threads) race; calls on one stream are ordered and safe.  The per-device
+ * set-up (context and the array's address on that device) runs in zbra_hip_init() or in any earlier
+ * call on the device; when this call is the first one on a device it runs the set-up itself, which
+ * creates a stream: call zbra_hip_init() beforehand where even that is not allowed. */
+#define ZBRA_HIP_NOALLOC_MAX_ARRAYS 4096
+#define ZBRA_HIP_NOALLOC_MAX_TILES (1u << 20)
+int zbra_hip_decode_batch_dev_noalloc(const zbra_array_desc *descs, size_t nd, zbra_dev_result *d_results, void *stream);
 
 /* compress_int_array on values already in HBM.  d_out must hold zbra_hip_encode_bound(n) bytes;
  * the encoded length is only known on the device: d_result->out_count (d_result must not be

@@ -68,6 +68,7 @@ SIGNATURES = {
     "zbra_hip_decode_offsets_dev": (C.c_int, [_p, _sz, _sz, _p, _p, _p]),
     "zbra_hip_enum_rows_dev": (C.c_int, [_p, _sz, _p, C.c_uint32, _p, _p, _p, _p, _p]),
     "zbra_hip_decode_batch_dev": (C.c_int, [C.POINTER(ArrayDesc), _sz, _p, _p]),
+    "zbra_hip_decode_batch_dev_noalloc": (C.c_int, [C.POINTER(ArrayDesc), _sz, _p, _p]),
     "zbra_hip_encode_dev": (C.c_int, [_p, _sz, C.c_uint32, _p, _sz, _p, _p]),
     "zbra_hip_encode_batch_dev": (C.c_int, [C.POINTER(EncodeDesc), _sz, _p, _p]),
     "zbra_hip_decode_batch": (C.c_int, [C.POINTER(ArrayDesc), _sz, C.POINTER(C.c_int)]),
@@ -109,6 +110,9 @@ ERR_INVALID_ARG = 5
 ERR_NO_DEVICE = 6
 ERR_FORMAT = 7
 ERR_UNKNOWN_TAG = 8
+ERR_NOALLOC_LIMIT = 9
+NOALLOC_MAX_ARRAYS = 4096
+NOALLOC_MAX_TILES = 1 << 20
 ERR_HIP_BASE = 100
 ELEM_I64 = 0
 ELEM_U32 = 1

@@ -29,7 +29,7 @@ def _raise(status: int):
     msg = _lib.strerror(status)
     if status in (_lib.ERR_SHORT_HEADER, _lib.ERR_SHORT_PACKED, _lib.ERR_TRUNCATED):
         raise DecompressionError(msg)
-    if status == _lib.ERR_INVALID_ARG:
+    if status in (_lib.ERR_INVALID_ARG, _lib.ERR_NOALLOC_LIMIT):
         raise ValueError(msg)
     raise DeviceError(f"{msg} (status {status})")
 

@@ -19,6 +19,21 @@
 
 namespace zbra {
 
+// ---- scratch of the entry point that allocates nothing ---------------------------------------
+//
+// zbra_hip_decode_batch_dev_noalloc keeps what zbra_hip_decode_batch_dev borrows from a workspace
+// slot (the decode plans, the tiles-per-array scan and the tile -> array table) in this array.
+// Every GPU the library runs on holds its own copy, at its own address, until the process ends.
+// Host code never uses the name `scratch` as an address: it is a host-side stand-in for the symbol.
+// The per-device address comes from hipGetSymbolAddress once per device (current_ctx below) and
+// is what the kernels get as an argument.
+struct NoAllocScratch {
+    DecodePlan plans[ZBRA_HIP_NOALLOC_MAX_ARRAYS];
+    uint64_t tile_start[ZBRA_HIP_NOALLOC_MAX_ARRAYS + 8];  // nd + 1 used
+    uint32_t tile_map[ZBRA_HIP_NOALLOC_MAX_TILES];
+};
+static __device__ __align__(256) unsigned char scratch[sizeof(NoAllocScratch)];
+
 static std::mutex g_ctx_mu;
 static std::map<int, DeviceCtx *> g_ctx;
 
@@ -36,6 +51,15 @@ int current_ctx(DeviceCtx **out) {
     c->device = dev;
     e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
     if (e != hipSuccess) { delete c; return hip_status(e); }
+    // this device's copy of `scratch` (device `dev` is current: hipGetDevice just said so)
+    void *sp = nullptr;
+    e = hipGetSymbolAddress(&sp, HIP_SYMBOL(scratch));
+    if (e != hipSuccess || !sp) {
+        (void)hipStreamDestroy(c->stream);
+        delete c;
+        return e != hipSuccess ? hip_status(e) : ZBRA_ERR_NO_DEVICE;
+    }
+    c->noalloc_scratch = sp;
     g_ctx[dev] = c;
     *out = c;
     return ZBRA_OK;
@@ -207,6 +231,68 @@ static int decode_batch_dev(DeviceCtx *ctx, const zbra_array_desc *descs, size_t
     }
     int st2 = ctx->release(s, stream);
     return st != ZBRA_OK ? st : st2;
+}
+
+// ---- decode, device-resident, no allocation --------------------------------------------------
+
+// Up to NOALLOC_CHUNK descriptors and their tile scan travel in the kernel arguments (about 3 KB),
+// so nothing is staged in pinned memory and no copy is enqueued: the call is kernel launches only.
+constexpr uint32_t NOALLOC_CHUNK = 64;
+struct NoAllocChunk {
+    zbra_array_desc d[NOALLOC_CHUNK];
+    uint64_t ts[NOALLOC_CHUNK + 1];  // tile_start of the chunk's arrays and of the one after
+};
+
+// Workgroup b handles array first + b of the submission: header parse, its tile_start entry (the
+// last workgroup also writes the entry after it) and its slice of the tile -> array table.
+__global__ __launch_bounds__(256) void plan_decode_noalloc_kernel(NoAllocChunk c, uint32_t first, uint32_t n, DecodePlan *__restrict__ plans,
+                                                                  uint64_t *__restrict__ tile_start, uint32_t *__restrict__ tile_map,
+                                                                  zbra_dev_result *results) {
+    const uint32_t b = blockIdx.x;
+    if (b >= n) return;
+    const uint32_t a = first + b;
+    const uint64_t t0 = c.ts[b], t1 = c.ts[b + 1];
+    if (threadIdx.x == 0) {
+        plan_one(c.d[b], plans + a, results ? results + a : nullptr);
+        tile_start[a] = t0;
+        if (b == n - 1) tile_start[a + 1] = t1;
+    }
+    for (uint64_t t = t0 + threadIdx.x; t < t1; t += blockDim.x) tile_map[t] = a;
+}
+
+static int decode_batch_dev_noalloc(DeviceCtx *ctx, const zbra_array_desc *descs, size_t nd, zbra_dev_result *d_results,
+                                    hipStream_t stream) {
+    if (nd == 0) return ZBRA_OK;
+    if (!descs) return ZBRA_ERR_INVALID_ARG;
+    if (nd > (size_t)ZBRA_HIP_NOALLOC_MAX_ARRAYS) return ZBRA_ERR_NOALLOC_LIMIT;
+    uint64_t ntiles = 0;
+    for (size_t i = 0; i < nd; i++) {
+        const zbra_array_desc &d = descs[i];
+        if (d.count > MAX_COUNT || d.kind > ZBRA_ELEM_U32) return ZBRA_ERR_INVALID_ARG;
+        if ((d.len && !d.data) || (d.count && d.len && !d.out)) return ZBRA_ERR_INVALID_ARG;
+        ntiles += decode_tiles_of(d.count, d.kind);
+    }
+    if (ntiles > (uint64_t)ZBRA_HIP_NOALLOC_MAX_TILES) return ZBRA_ERR_NOALLOC_LIMIT;
+    NoAllocScratch *sc = (NoAllocScratch *)ctx->noalloc_scratch;  // this device's address, never the symbol's name
+    // Nothing in the scratch has to start at zero: plans[0, nd), tile_start[0, nd] and
+    // tile_map[0, ntiles) are all written by this call's plan kernels before the tile kernel,
+    // which reads nothing else, runs behind them on the same stream.
+    uint64_t run = 0;
+    for (size_t first = 0; first < nd; first += NOALLOC_CHUNK) {
+        NoAllocChunk c;
+        const uint32_t n = (uint32_t)(nd - first < NOALLOC_CHUNK ? nd - first : NOALLOC_CHUNK);
+        for (uint32_t b = 0; b < n; b++) {
+            c.d[b] = descs[first + b];
+            c.ts[b] = run;
+            run += decode_tiles_of(descs[first + b].count, descs[first + b].kind);
+        }
+        c.ts[n] = run;
+        for (uint32_t b = n; b < NOALLOC_CHUNK; b++) { std::memset(&c.d[b], 0, sizeof(c.d[b])); c.ts[b + 1] = run; }
+        hipLaunchKernelGGL(plan_decode_noalloc_kernel, dim3(n), dim3(256), 0, stream, c, (uint32_t)first, n, sc->plans, sc->tile_start,
+                           sc->tile_map, d_results);
+    }
+    if (ntiles) launch_decode(stream, sc->plans, sc->tile_start, sc->tile_map, (uint32_t)nd, ntiles);
+    return hip_status(hipGetLastError());
 }
 
 // ---- encode, device-resident ---------------------------------------------------------------
@@ -664,6 +750,7 @@ const char *zbra_hip_strerror(int status) {
         case ZBRA_ERR_NO_DEVICE: return "No usable HIP device";
         case ZBRA_ERR_FORMAT: return "Invalid .zbra image (magic number, tag or length)";
         case ZBRA_ERR_UNKNOWN_TAG: return "enum tag carried by no variant";                // striped.rs:352-358
+        case ZBRA_ERR_NOALLOC_LIMIT: return "Submission exceeds the fixed scratch of the no-allocation entry point (arrays or tiles)";
         default:
             if (status >= ZBRA_ERR_HIP_BASE) return hipGetErrorString((hipError_t)(status - ZBRA_ERR_HIP_BASE));
             return "unknown status";
@@ -900,6 +987,14 @@ int zbra_hip_decode_batch_dev(const zbra_array_desc *descs, size_t nd, zbra_dev_
     DeviceCtx *ctx;
     ZBRA_TRY(current_ctx(&ctx));
     return decode_batch_dev(ctx, descs, nd, d_results, (hipStream_t)stream);
+}
+
+int zbra_hip_decode_batch_dev_noalloc(const zbra_array_desc *descs, size_t nd, zbra_dev_result *d_results, void *stream) {
+    // The context (and with it this device's scratch address) exists after zbra_hip_init() or any
+    // earlier call on this device; only when this is the very first call does it run the set-up.
+    DeviceCtx *ctx;
+    ZBRA_TRY(current_ctx(&ctx));
+    return decode_batch_dev_noalloc(ctx, descs, nd, d_results, (hipStream_t)stream);
 }
 
 int zbra_hip_encode_dev(const void *d_values, size_t n, uint32_t kind, uint8_t *d_out, size_t cap,

@@ -68,6 +68,7 @@ struct DeviceCtx {
     std::mutex mu;              // guards slots
     std::vector<Slot *> slots;  // pointers stay valid while the vector grows
     std::mutex host_mu;         // serialises host-pointer calls: they share the arenas and the stream
+    void *noalloc_scratch = nullptr;  // this device's address of the library's static scratch array (set once, at creation)
     hipStream_t stream = nullptr;
     hipStream_t stream2 = nullptr;            // the way back of a piecewise host decode
     hipEvent_t piece_done[4] = {nullptr, nullptr, nullptr, nullptr};

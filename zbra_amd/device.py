@@ -110,6 +110,16 @@ def decode_batch_dev(descs, results: torch.Tensor = None, stream=None):
         _raise(st)
 
 
+def decode_batch_dev_noalloc(descs, results: torch.Tensor = None, stream=None):
+    """zbra_hip_decode_batch_dev_noalloc: decode_batch_dev for callers that cannot allocate (kernel
+    launches only, fixed scratch inside the library; at most _lib.NOALLOC_MAX_ARRAYS arrays and
+    _lib.NOALLOC_MAX_TILES tiles per call; calls that overlap on one GPU race)."""
+    st = lib.zbra_hip_decode_batch_dev_noalloc(descs, len(descs), results.data_ptr() if results is not None else None,
+                                               _stream_handle(stream))
+    if st:
+        _raise(st)
+
+
 def encode_dev(values: torch.Tensor, out: torch.Tensor, result: torch.Tensor, stream=None):
     """compress_int_array (compression.rs:271-292) on values resident in HBM; the encoded length
     lands in result (out_count)."""
