@@ -324,56 +324,72 @@ static int encode_batch_dev(DeviceCtx *ctx, const EncodeItem *items, size_t nd, 
         if (items[i].n > MAX_COUNT || items[i].kind > KIND_U64_PLAIN) return ZBRA_ERR_INVALID_ARG;
         if (items[i].n && (!items[i].values || (mode == ENCODE_FULL && !frames && !items[i].out))) return ZBRA_ERR_INVALID_ARG;
     }
-    const size_t off_ts = align_up(nd * sizeof(EncodeJob), 64);
-    const size_t off_list = align_up(off_ts + (nd + 1) * sizeof(uint64_t), 64);  // arrays that may need select passes
-    const size_t off_hist = align_up(off_list + nd * sizeof(uint32_t), 256);
-    const size_t off_ctr = off_hist + nd * BINS * sizeof(uint32_t);  // zeroed together with the histograms
-    const size_t off_pend = off_ctr + nd * sizeof(BracketCounters);  // {count, arrays...} left to the pass-per-launch select; zeroed too
-    const size_t total = off_pend + (nd + 1) * sizeof(uint32_t);
+    const bool bracket = encode_bracket_enabled();
+    const uint64_t small_max = small_select_keys();
+    // Which arrays need what.  "listed": may go through the bracket pass and the select (arrays of
+    // up to SAMPLE values are sorted whole by the sample kernel and need no pass; plain u64 values
+    // have no median).  "long": may have too much to read for one finishing workgroup, so the
+    // many-workgroup levels are launched and these arrays get their histograms and key buffer.
+    auto listed = [&](const EncodeItem &it) { return it.n && it.kind != KIND_U64_PLAIN && (!bracket || it.n > (uint64_t)SAMPLE); };
+    auto is_long = [&](const EncodeItem &it) { return listed(it) && it.n > (uint64_t)CAND_DIV * small_max; };
     // candidate lists of the bracket select: CAND_SEGS segments, n/CAND_DIV values in all, per array
     // that is long enough for it
-    const bool bracket = encode_bracket_enabled();
     auto seg_cap_of = [&](const EncodeItem &it) -> uint64_t {
         if (!bracket || it.kind == KIND_U64_PLAIN || it.n <= (uint64_t)SAMPLE) return 0;
         return it.n / CAND_DIV / CAND_SEGS / TILE * TILE;
     };
+    uint32_t n_list = 0, n_big = 0;
     size_t scratch_bytes = 0;
-    for (size_t i = 0; i < nd; i++) scratch_bytes += seg_cap_of(items[i]) * CAND_SEGS * sizeof(int64_t);
+    for (size_t i = 0; i < nd; i++) {
+        n_list += listed(items[i]) ? 1u : 0u;
+        n_big += is_long(items[i]) ? 1u : 0u;
+        scratch_bytes += seg_cap_of(items[i]) * CAND_SEGS * sizeof(int64_t);
+    }
+    const size_t off_small = align_up(scratch_bytes, 256);  // gathered keys of the long arrays, behind the candidate lists
+    scratch_bytes = off_small + (size_t)n_big * GATHER_CAP * sizeof(uint64_t);
+    const size_t off_ts = align_up(nd * sizeof(EncodeJob), 64);
+    const size_t off_list = align_up(off_ts + (nd + 1) * sizeof(uint64_t), 64);  // the listed arrays
+    const size_t host_bytes = off_list + (size_t)n_list * sizeof(uint32_t);      // what the host fills
+    // device only, zeroed by every call: histograms and counters of the listed arrays, level
+    // histograms of the long ones, the list of arrays left to the levels {count, arrays...}
+    const size_t off_hist = align_up(host_bytes, 256);
+    const size_t off_ctr = off_hist + (size_t)n_list * BINS * sizeof(uint32_t);
+    const size_t off_lvl = off_ctr + (size_t)n_list * sizeof(BracketCounters);
+    const size_t off_pend = off_lvl + (size_t)n_big * SEL_LEVELS * BINS * sizeof(uint32_t);
+    const size_t total = off_pend + ((size_t)n_big + 1) * sizeof(uint32_t);
     Slot *s;
-    ZBRA_TRY(ctx->acquire(total, &s, scratch_bytes, off_list + nd * sizeof(uint32_t)));  // histograms and counters: device only
+    ZBRA_TRY(ctx->acquire(total, &s, scratch_bytes, host_bytes));
     EncodeJob *h_jobs = (EncodeJob *)s->host;
     uint64_t *h_ts = (uint64_t *)((char *)s->host + off_ts);
     uint32_t *h_list = (uint32_t *)((char *)s->host + off_list);
-    const uint64_t small_max = small_select_keys();
-    // digits a pending array can have: u32 inputs span less than 2^32, three digits of twelve bits
-    uint32_t big_passes = (32 + DIGIT_BITS - 1) / DIGIT_BITS;
-    uint32_t n_list = 0, n_big = 0;  // n_big: listed arrays that one workgroup may not be able to finish
+    uint32_t i_list = 0, i_big = 0;
     uint64_t run = 0;
     size_t scratch_off = 0;
     for (size_t i = 0; i < nd; i++) {
         EncodeJob j;
         std::memset(&j, 0, sizeof(j));
         j.values = items[i].values; j.out = items[i].out; j.n = items[i].n; j.cap = items[i].cap; j.kind = items[i].kind;
-        j.min_b = ~0ull; j.max_b = 0; j.next_above = ~0ull;
+        j.min_b = ~0ull; j.max_b = 0; j.next_above = ~0ull; j.above_key = ~0ull;
+        for (int l = 0; l < SEL_LEVELS; l++) j.match_min[l] = ~0ull;  // match_max starts at 0
         j.sel_values = items[i].values; j.sel_n = items[i].n; j.sel_kind = items[i].kind;
-        j.counters = (BracketCounters *)((char *)s->dev + off_ctr) + i;
         j.seg_cap = seg_cap_of(items[i]);
         if (j.seg_cap) {
             j.cand = (int64_t *)((char *)s->scratch + scratch_off);
             scratch_off += j.seg_cap * CAND_SEGS * sizeof(int64_t);
         }
+        if (listed(items[i])) {
+            j.hist = (uint32_t *)((char *)s->dev + off_hist) + (size_t)i_list * BINS;
+            j.counters = (BracketCounters *)((char *)s->dev + off_ctr) + i_list;
+            h_list[i_list++] = (uint32_t)i;
+            if (is_long(items[i])) {
+                j.lvl_hist = (uint32_t *)((char *)s->dev + off_lvl) + (size_t)i_big * SEL_LEVELS * BINS;
+                j.small = (uint64_t *)((char *)s->scratch + off_small) + (size_t)i_big * GATHER_CAP;
+                i_big++;
+            }
+        }
         h_jobs[i] = j;
         h_ts[i] = run;
         run += tiles_of(items[i].n);
-        // arrays of up to SAMPLE values are sorted whole by the sample kernel and need no pass
-        if (items[i].n && items[i].kind != KIND_U64_PLAIN && (!bracket || items[i].n > (uint64_t)SAMPLE)) {
-            h_list[n_list++] = (uint32_t)i;
-            // only longer arrays can be left to the pass-per-launch kernels (enc_select_small_kernel)
-            if (items[i].n > (uint64_t)CAND_DIV * small_max) {
-                n_big++;
-                if (items[i].kind != ZBRA_ELEM_U32) big_passes = (uint32_t)MAX_PASSES;
-            }
-        }
     }
     h_ts[nd] = run;
     const uint64_t ntiles = run;
@@ -381,43 +397,38 @@ static int encode_batch_dev(DeviceCtx *ctx, const EncodeItem *items, size_t nd, 
     const uint32_t *d_list = (const uint32_t *)((char *)s->dev + off_list);
     uint32_t *d_pend = (uint32_t *)((char *)s->dev + off_pend);
     const uint64_t *d_ts = (const uint64_t *)((char *)s->dev + off_ts);
-    uint32_t *d_hist = (uint32_t *)((char *)s->dev + off_hist);
-    int st = hip_status(hipMemcpyAsync(s->dev, s->host, off_list + nd * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
-    if (st == ZBRA_OK) st = hip_status(hipMemsetAsync(d_hist, 0, total - off_hist, stream));
+    int st = hip_status(hipMemcpyAsync(s->dev, s->host, host_bytes, hipMemcpyHostToDevice, stream));
+    if (st == ZBRA_OK) st = hip_status(hipMemsetAsync((char *)s->dev + off_hist, 0, total - off_hist, stream));
     if (st == ZBRA_OK) {
         // Resident workgroups of the run-based passes.  Measured on the encode of one 2^28-row
         // column: 512 -> 0.877 ms, 768 -> 0.828, 1024 -> 0.838, 2048 -> 0.877, 4096 -> 0.895; batches
         // of a thousand arrays prefer 2048 (config 3: 5.41 ms against 5.69 at 1024).
         const unsigned gs = grid_for(ntiles, nd == 1 ? STREAM_GRID_CAP / 2 : STREAM_GRID_CAP);
         const unsigned ga = (unsigned)((nd + 255) / 256);
-        // workgroups of a pass-per-launch histogram pass, dealt to the arrays still pending
+        // workgroups of a many-workgroup select level, dealt to the arrays it finds pending
         const unsigned gh = n_big >= 512 ? 8192u : 4096u;
         if (ntiles) {
             hipLaunchKernelGGL(enc_sample_kernel, dim3((unsigned)nd), dim3(SAMPLE_THREADS), 0, stream, d_jobs, (uint32_t)nd,
                                bracket ? 1u : 0u);
             // arrays outside the list (sorted whole by the sample kernel, or plain u64) need
-            // neither the bracket pass nor any select pass: a submission of short arrays is five
-            // launches, not nineteen
+            // neither the bracket pass nor any select launch
             if (n_list)
-                hipLaunchKernelGGL(enc_bracket_kernel, dim3(gs), dim3(THREADS), 0, stream, d_jobs, d_ts, (uint32_t)nd, ntiles, d_hist);
+                hipLaunchKernelGGL(enc_bracket_kernel, dim3(gs), dim3(THREADS), 0, stream, d_jobs, d_ts, (uint32_t)nd, ntiles);
         }
-        hipLaunchKernelGGL(enc_setup_kernel, dim3((unsigned)nd), dim3(THREADS), 0, stream, d_jobs, (uint32_t)nd, d_hist);
+        hipLaunchKernelGGL(enc_setup_kernel, dim3((unsigned)nd), dim3(THREADS), 0, stream, d_jobs, (uint32_t)nd, d_pend, small_max);
         if (ntiles) {
-            // every listed array whose select reads few enough keys is finished by one workgroup in
-            // one launch and the others are put on the pending list; the pass-per-launch kernels
-            // are only launched when an array could be too long for that (its length says so),
-            // and end at their first load when none was
+            // the levels are only launched when an array could be too long for one finishing
+            // workgroup (its length says so), and end at their first load when none was
+            for (uint32_t L = 1; n_big && L <= (uint32_t)SEL_LEVELS; L++)
+                hipLaunchKernelGGL(enc_level_kernel, dim3(gh), dim3(THREADS), 0, stream, d_jobs, d_pend, L);
             if (n_list)
-                hipLaunchKernelGGL(enc_select_small_kernel, dim3(n_list), dim3(THREADS), 0, stream, d_jobs, d_list, n_list, d_hist, d_pend, small_max);
-            for (uint32_t pass = 0; n_big && pass < big_passes; pass++) {
-                hipLaunchKernelGGL(enc_hist_kernel, dim3(gh), dim3(THREADS), 0, stream, d_jobs, d_pend, d_hist, pass);
-                hipLaunchKernelGGL(enc_select_kernel, dim3(n_big), dim3(THREADS), 0, stream, d_jobs, d_pend, d_hist, pass);
-            }
+                hipLaunchKernelGGL(enc_finish_select_kernel, dim3(n_list), dim3(THREADS), 0, stream, d_jobs, d_list, n_list);
             if (mode == ENCODE_FULL) {
-                // Few arrays of a batch need this pass (a span of 2^63 or more), and a contiguous
-                // run per resident workgroup would leave each of them to the two or three
-                // workgroups whose runs it crosses: short runs of 16 tiles instead, most of which
-                // end at their first look (a thousand 2^20-row arrays, two of them wide: 187 -> 47 us).
+                // Few arrays of a batch need this pass (a span of 2^63 or more whose extremes do not
+                // already take 64 bits), and a contiguous run per resident workgroup would leave
+                // each of them to the two or three workgroups whose runs it crosses: short runs of
+                // 16 tiles instead, most of which end at their first look (a thousand 2^20-row
+                // arrays, two of them wide: 187 -> 47 us).
                 const unsigned go = nd == 1 ? gs : grid_for(ntiles / 16 + 1, 32768);
                 hipLaunchKernelGGL(enc_or_kernel, dim3(go), dim3(THREADS), 0, stream, d_jobs, d_ts, (uint32_t)nd, ntiles);
             }

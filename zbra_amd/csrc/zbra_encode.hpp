@@ -21,7 +21,11 @@
 //            radix select below runs on the histogram / the compacted list; if not (a sample that
 //            misled, more than n/4 candidates) it runs on the whole array, as it would without
 //            the sample.  Either way the result is exact.
-//   select   radix select on key = v - base, 12 bits a pass, ceil(bits(span)/12) passes.
+//   select   radix select on key = v - base, 12 bits a digit.  The bracket pass itself counts the
+//            first digit of a wide bracket; a short source is finished by one workgroup in one
+//            launch; a long one gets up to three launches of many workgroups, each of which either
+//            counts the next digit or, as soon as at most 2048 keys share the resolved digits,
+//            gathers those keys for the finishing workgroup to sort.
 // Every kernel works on a whole submission (many arrays) through the same tile -> array map the
 // decoder uses, and every pass that an array does not need skips that array's memory.
 #pragma once
@@ -42,12 +46,11 @@ struct EncodeJob {
     uint64_t n;
     uint64_t cap;
     uint32_t kind;
-    uint32_t passes;     // radix-select passes this array needs
+    uint32_t passes;     // digits of DIGIT_BITS bits in a key of the radix select (key < 2^(DIGIT_BITS * passes))
     uint64_t min_b;      // min / max of (v ^ SIGN): unsigned order of the biased value = signed order
     uint64_t max_b;
-    uint64_t prefix;     // resolved high digits of the key of a
-    uint64_t k;          // rank of a among the elements that share `prefix`
-    uint64_t next_above; // smallest key whose high digits exceed `prefix` (last pass)
+    uint64_t next_above; // smallest key above the bracket (in key space once the bracket is verified), ~0 if none
+    unsigned long long above_key;  // smallest key above the keys that share the resolved digits, from the select's last read of the source
     uint64_t or_bits;    // OR of zigzag(v - mid), wide spans only
     int64_t midpoint;
     uint32_t width;
@@ -69,6 +72,34 @@ struct EncodeJob {
     int64_t *cand;
     uint64_t seg_cap;    // a multiple of TILE; 0 = no list (short array or bracket select off)
     struct BracketCounters *counters;
+    // Radix select.  What is read: the candidate list (mode SEL_BRACKET_COMPACT) or the array itself,
+    // of which only values with flo <= (v ^ SIGN) <= fhi count (the verified bracket whose list
+    // overflowed, or everything).
+    uint64_t flo, fhi;
+    uint32_t *hist;      // BINS counters: the bracket pass's histogram (exact keys of a narrow bracket, first digit of a wide one)
+    uint32_t *lvl_hist;  // SEL_LEVELS x BINS counters of the many-workgroup levels (long arrays only)
+    uint64_t *small;     // GATHER_CAP keys gathered by a level for the finishing workgroup (long arrays only)
+    uint32_t small_n;
+    uint32_t pending;    // 1 = on the list of the many-workgroup levels
+    // smallest / largest key among those whose next digit level L counted (all equal: a run of one
+    // value, which needs no further digit)
+    unsigned long long match_min[3], match_max[3];
+    struct SelState {
+        uint64_t prefix;  // resolved high digits of the key of a
+        uint64_t k;       // rank of a among the keys that share `prefix`
+        uint64_t cnt;     // how many keys share `prefix`
+        uint32_t lv;      // digits resolved
+        uint32_t action;  // SelAction: what the launch that wrote this state left behind
+    } S[4];               // S[0]: after set-up; S[L]: after level L (SEL_LEVELS of them)
+};
+constexpr int SEL_LEVELS = 3;
+static_assert(SEL_LEVELS == sizeof(EncodeJob::match_min) / sizeof(unsigned long long), "one min / max pair per level");
+constexpr uint32_t GATHER_CAP = 2048;  // keys a level gathers: what the finishing workgroup sorts in LDS
+enum SelAction : uint32_t {
+    ACT_NONE = 0,    // nothing counted yet: the next step starts from this state
+    ACT_HIST = 1,    // digit `lv` of the keys that share `prefix` is counted: in `hist` for S[0], else in lvl_hist[L - 1]
+    ACT_GATHER = 2,  // the `cnt` keys that share `prefix` are in `small`
+    ACT_DONE = 3     // the midpoint is known
 };
 
 constexpr int CAND_SEGS = 16;
@@ -91,7 +122,11 @@ constexpr int SAMPLE = 4096;          // sample keys sorted in LDS (32 KiB)
 constexpr int SAMPLE_THREADS = 1024;  // lanes of the sorting workgroup
 constexpr int SAMPLE_MARGIN = 128;    // sample ranks either side: 4 sigma, sigma = sqrt(SAMPLE)/2 = 32
 constexpr int CAND_DIV = 4;           // candidate list capacity = n / CAND_DIV (a bracket holds ~6 % of n)
-constexpr int CAND_LDS = 2048;        // candidates a workgroup stages in LDS between flushes (>= 1 tile)
+#ifndef ZBRA_CAND_LDS
+#define ZBRA_CAND_LDS 2048
+#endif
+constexpr int CAND_LDS = ZBRA_CAND_LDS;  // candidates a workgroup stages in LDS between flushes (a quarter of them per wave)
+constexpr int CAND_PARTS = CAND_LDS >= 2048 ? 2 : 4;  // a tile's values are appended in this many parts, with a look at the room before each
 
 __device__ __forceinline__ int64_t load_value(const EncodeJob &j, uint64_t i) {
     return j.kind != ZBRA_ELEM_U32 ? gptr<int64_t>(j.values)[i] : (int64_t)gptr<uint32_t>(j.values)[i];
@@ -201,11 +236,19 @@ __device__ __forceinline__ void set_midpoint(EncodeJob &j, int64_t a, int64_t b,
         mid = (int64_t)((uint64_t)a + (uint64_t)(diff / 2));        // a.wrapping_add(diff / 2), `/` truncates
     }
     j.midpoint = mid;
+    const int64_t vmin = (int64_t)(j.min_b ^ SIGN), vmax = (int64_t)(j.max_b ^ SIGN);
+    const uint64_t z0 = zigzag_encode64((int64_t)((uint64_t)vmin - (uint64_t)mid));
+    const uint64_t z1 = zigzag_encode64((int64_t)((uint64_t)vmax - (uint64_t)mid));
+    const uint64_t z = z0 > z1 ? z0 : z1;
     if (!j.need_or) {
-        const int64_t vmin = (int64_t)(j.min_b ^ SIGN), vmax = (int64_t)(j.max_b ^ SIGN);
-        const uint64_t z0 = zigzag_encode64((int64_t)((uint64_t)vmin - (uint64_t)mid));
-        const uint64_t z1 = zigzag_encode64((int64_t)((uint64_t)vmax - (uint64_t)mid));
-        j.width = width_of(z0 > z1 ? z0 : z1);
+        j.width = width_of(z);
+    } else if (z >= SIGN) {
+        // A span of 2^63 or more lets v - mid wrap, so the extremes need not give the largest
+        // zig-zag value; but they are values of the array, and when one of them already needs all
+        // 64 bits nothing can need more: the OR pass over the array is not needed (a full-range
+        // column, f64 bit patterns).  [i64::MIN, i64::MAX] is the case that still takes it.
+        j.width = 64;
+        j.need_or = 0;
     }
 }
 
@@ -290,7 +333,9 @@ __global__ __launch_bounds__(SAMPLE_THREADS) void enc_sample_kernel(EncodeJob *_
     const uint64_t r = (uint64_t)(((unsigned __int128)k * sample) / n);  // expected sample rank of a
     job.lo_b = r >= (uint64_t)margin ? sk[r - margin] : 0;
     job.hi_b = r + margin < (uint64_t)sample ? sk[r + margin] : ~0ull;
-    if (job.hi_b - job.lo_b < (uint64_t)BINS) job.mode = SEL_BRACKET_HIST;
+    job.key_base = job.lo_b;  // keys of a bracket select: (v ^ SIGN) - lo_b
+    job.passes = (bit_length64(job.hi_b - job.lo_b) + DIGIT_BITS - 1) / DIGIT_BITS;
+    if (job.hi_b - job.lo_b < (uint64_t)BINS) { job.mode = SEL_BRACKET_HIST; job.passes = 1; }
     else if (job.seg_cap) job.mode = SEL_BRACKET_COMPACT;  // else stays SEL_FULL: no room for candidates
 }
 
@@ -313,7 +358,8 @@ constexpr uint32_t SEL_BRACKET_MICRO = 100;  // template tag only: a histogram-m
 // compile-time so that the loop body is straight-line code with one branch (the append).
 template <uint32_t MODE, bool WHOLE, int E0, int E1>
 __device__ __forceinline__ void bracket_values(const int64_t (&x)[2 * PAIRS], uint32_t kind, uint64_t v0, uint64_t n, uint64_t lo_b,
-                                               uint64_t hi_b, BracketAcc &acc, uint32_t *lh, int64_t *lcand, uint32_t *lcount) {
+                                               uint64_t hi_b, BracketAcc &acc, uint32_t *lh, int64_t *lcand, uint32_t *lcount,
+                                               uint32_t digit_shift = 0) {
 #pragma unroll
     for (int e = E0; e < E1; ++e) {
         const uint64_t b = (uint64_t)x[e] ^ SIGN;
@@ -331,7 +377,10 @@ __device__ __forceinline__ void bracket_values(const int64_t (&x)[2 * PAIRS], ui
             } else if (MODE == SEL_BRACKET_COMPACT) {
                 // wave-private staging: the ballot gives every lane its slot, no atomic, no barrier
                 const uint64_t m = __ballot(inside);
-                if (inside) lcand[*lcount + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u))] = x[e];
+                if (inside) {
+                    lcand[*lcount + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u))] = x[e];
+                    atomicAdd(&lh[(uint32_t)((b - lo_b) >> digit_shift)], 1u);  // first digit of the select's key
+                }
                 *lcount += (uint32_t)__popcll(m);
             } else if (inside) {
                 atomicAdd(&lh[(uint32_t)(b - lo_b)], 1u);
@@ -342,13 +391,11 @@ __device__ __forceinline__ void bracket_values(const int64_t (&x)[2 * PAIRS], ui
 
 __global__ __launch_bounds__(THREADS) void enc_bracket_kernel(EncodeJob *__restrict__ jobs,
                                                                const uint64_t *__restrict__ tile_start, uint32_t nd,
-                                                               uint64_t ntiles, uint32_t *__restrict__ hist) {
-    // An array is in histogram mode or in candidate mode, never both: the two images share LDS.
-    // Invariant between runs: the histogram part is all zero.
-    __shared__ __attribute__((aligned(16))) int64_t pool[CAND_LDS];
-    static_assert(sizeof(int64_t) * CAND_LDS >= sizeof(uint32_t) * BINS && CAND_LDS >= TILE, "LDS pool too small");
-    uint32_t *lh = (uint32_t *)pool;
-    int64_t *lcand = pool;
+                                                               uint64_t ntiles) {
+    // Histogram (exact keys of a narrow bracket; first digit of the keys of a wide one, whose
+    // values are also staged as candidates).  Invariant between runs: the histogram is all zero.
+    __shared__ uint32_t lh[BINS];
+    __shared__ __attribute__((aligned(16))) int64_t lcand[CAND_LDS];
     __shared__ unsigned long long lbelow, linb; // this run's counts
     for (uint32_t b = threadIdx.x; b < BINS; b += THREADS) lh[b] = 0;
     if (threadIdx.x == 0) { lbelow = 0; linb = 0; }
@@ -374,7 +421,9 @@ __global__ __launch_bounds__(THREADS) void enc_bracket_kernel(EncodeJob *__restr
         // lanes) when less than half a tile's worth of room is left.  No lane of another wave is
         // involved, so the tile loop has no workgroup barrier.
         constexpr uint32_t WAVES = THREADS / 64, WAVE_CAP = CAND_LDS / WAVES;
-        static_assert(WAVE_CAP >= 2 * (TILE / 2 / WAVES), "a wave appends at most TILE / 2 / WAVES values between two looks");
+        static_assert(WAVE_CAP >= 2 * (TILE / CAND_PARTS / WAVES), "a wave appends at most TILE / CAND_PARTS / WAVES values between two looks");
+        static_assert(PAIRS == 4, "a tile is handled in halves or quarters of its eight values per lane");
+        const uint32_t dsh = DIGIT_BITS * (job.passes - 1);  // wide bracket: the key's first digit
         const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
         int64_t *wstage = lcand + wave * WAVE_CAP;
         uint32_t wcount = 0;  // uniform within the wave
@@ -421,13 +470,21 @@ __global__ __launch_bounds__(THREADS) void enc_bracket_kernel(EncodeJob *__restr
                 if (whole) bracket_values<SEL_BRACKET_MICRO, true, 0, 2 * PAIRS>(x, kind, v0, n, lo_b, hi_b, acc, lh, nullptr, nullptr);
                 else bracket_values<SEL_BRACKET_MICRO, false, 0, 2 * PAIRS>(x, kind, v0, n, lo_b, hi_b, acc, lh, nullptr, nullptr);
             } else {
-                // a wave appends at most TILE / 2 / WAVES values per half tile
-                if (wcount + TILE / 2 / WAVES > WAVE_CAP) flush_wave();
-                if (whole) bracket_values<SEL_BRACKET_COMPACT, true, 0, PAIRS>(x, kind, v0, n, lo_b, hi_b, acc, lh, wstage, &wcount);
-                else bracket_values<SEL_BRACKET_COMPACT, false, 0, PAIRS>(x, kind, v0, n, lo_b, hi_b, acc, lh, wstage, &wcount);
-                if (wcount + TILE / 2 / WAVES > WAVE_CAP) flush_wave();
-                if (whole) bracket_values<SEL_BRACKET_COMPACT, true, PAIRS, 2 * PAIRS>(x, kind, v0, n, lo_b, hi_b, acc, lh, wstage, &wcount);
-                else bracket_values<SEL_BRACKET_COMPACT, false, PAIRS, 2 * PAIRS>(x, kind, v0, n, lo_b, hi_b, acc, lh, wstage, &wcount);
+                // a wave appends at most TILE / CAND_PARTS / WAVES values per part of a tile
+#define ZBRA_COMPACT_PART(E0, E1)                                                                                                  \
+    if (wcount + TILE / CAND_PARTS / WAVES > WAVE_CAP) flush_wave();                                                                \
+    if (whole) bracket_values<SEL_BRACKET_COMPACT, true, E0, E1>(x, kind, v0, n, lo_b, hi_b, acc, lh, wstage, &wcount, dsh);       \
+    else bracket_values<SEL_BRACKET_COMPACT, false, E0, E1>(x, kind, v0, n, lo_b, hi_b, acc, lh, wstage, &wcount, dsh);
+                if (CAND_PARTS == 4) {
+                    ZBRA_COMPACT_PART(0, 2)
+                    ZBRA_COMPACT_PART(2, 4)
+                    ZBRA_COMPACT_PART(4, 6)
+                    ZBRA_COMPACT_PART(6, 8)
+                } else {
+                    ZBRA_COMPACT_PART(0, 4)
+                    ZBRA_COMPACT_PART(4, 8)
+                }
+#undef ZBRA_COMPACT_PART
             }
         }
         // min / max: most waves cannot improve on what is already there: look before queueing an
@@ -446,13 +503,9 @@ __global__ __launch_bounds__(THREADS) void enc_bracket_kernel(EncodeJob *__restr
                 unsigned long long *pabove = (unsigned long long *)&jobs[a].next_above;
                 if (above < __hip_atomic_load(pabove, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMin(pabove, (unsigned long long)above);
             }
-            if (mode == SEL_BRACKET_COMPACT) {
-                flush_wave();
-                __syncthreads();  // every wave has emptied its part of the pool
-                for (uint32_t b = threadIdx.x; b < BINS; b += THREADS) lh[b] = 0;  // restore the invariant
-            }
+            if (mode == SEL_BRACKET_COMPACT) flush_wave();
             if (mode == SEL_BRACKET_MICRO) {  // sum the lanes' private columns into the array's histogram
-                uint32_t *gh = hist + (size_t)a * BINS;
+                uint32_t *gh = job.hist;
 #pragma unroll
                 for (uint32_t q = 0; q < MICRO_KEYS; q++) {
                     uint32_t c = lh[q * THREADS + threadIdx.x];
@@ -463,8 +516,8 @@ __global__ __launch_bounds__(THREADS) void enc_bracket_kernel(EncodeJob *__restr
                 }
             }
             __syncthreads();
-            if (mode == SEL_BRACKET_HIST) {
-                uint32_t *gh = hist + (size_t)a * BINS;
+            if (mode == SEL_BRACKET_HIST || mode == SEL_BRACKET_COMPACT) {
+                uint32_t *gh = job.hist;
                 for (uint32_t b = threadIdx.x; b < BINS; b += THREADS) {
                     const uint32_t c = lh[b];
                     if (c) { atomicAdd(&gh[b], c); lh[b] = 0; }
@@ -491,181 +544,12 @@ __global__ __launch_bounds__(THREADS) void enc_bracket_kernel(EncodeJob *__restr
 
 // ---- 3. verify the bracket, set up the radix select -------------------------------------------
 
-// One workgroup per array.
-__global__ __launch_bounds__(THREADS) void enc_setup_kernel(EncodeJob *__restrict__ jobs, uint32_t nd,
-                                                             uint32_t *__restrict__ hist) {
-    const uint32_t a = blockIdx.x;
-    if (a >= nd) return;
-    EncodeJob &j = jobs[a];
-    __shared__ uint32_t clear_hist;
-    if (threadIdx.x == 0) {
-        clear_hist = 0;
-        if (j.n == 0) {
-            j.passes = 0;
-        } else if (j.kind == KIND_U64_PLAIN) {
-            j.passes = 0; j.need_or = 1; j.midpoint = 0;
-        } else if (j.mode != SEL_DONE) {
-            const uint64_t span = j.max_b - j.min_b;
-            j.need_or = span >= SIGN;
-            j.prefix = 0;
-            const uint64_t k = (j.n - 1) / 2;  // rank of a: n/2 - 1 for even n, n/2 for odd n
-            bool whole_list = true;
-            if (j.mode != SEL_FULL) {
-                j.below = 0; j.inb = 0;
-                for (int sgm = 0; sgm < CAND_SEGS; sgm++) {
-                    j.below += j.counters->slot[sgm].below;
-                    j.inb += j.counters->slot[sgm].inb;
-                    whole_list = whole_list && j.counters->slot[sgm].cand_count <= j.seg_cap;
-                }
-            }
-            // Rank k must fall inside the bracket (rank k+1, for even n, may also be the smallest
-            // value above it), and the candidate list must be whole.
-            bool ok = j.mode != SEL_FULL && k >= j.below && k < j.below + j.inb;
-            if (ok && j.mode == SEL_BRACKET_COMPACT) ok = whole_list;
-            if (ok) {
-                // the histogram was built on keys b - lo_b; a candidate list may use the tighter base
-                j.key_base = j.mode == SEL_BRACKET_HIST || j.lo_b > j.min_b ? j.lo_b : j.min_b;
-                j.k = k - j.below;
-                if (j.next_above != ~0ull) j.next_above -= j.key_base;  // into key space
-                const uint64_t bspan = (j.hi_b < j.max_b ? j.hi_b : j.max_b) - j.key_base;
-                j.passes = (bit_length64(bspan) + DIGIT_BITS - 1) / DIGIT_BITS;
-                if (j.passes == 0) j.passes = 1;  // a one-key bracket still goes through select
-                if (j.mode == SEL_BRACKET_HIST) {
-                    j.passes = 1;  // the bracket pass already filled the histogram: select only
-                    j.sel_values = j.values; j.sel_n = 0; j.sel_kind = j.kind;  // nothing left to read
-                } else {
-                    // the segmented list, seen as one index space with gaps
-                    j.sel_values = j.cand; j.sel_n = j.seg_cap * CAND_SEGS; j.sel_kind = ZBRA_ELEM_I64;
-                }
-            } else {
-                if (j.mode == SEL_BRACKET_HIST) clear_hist = 1;
-                j.mode = SEL_FULL;
-                j.key_base = j.min_b;
-                j.k = k;
-                j.next_above = ~0ull;
-                j.passes = (bit_length64(span) + DIGIT_BITS - 1) / DIGIT_BITS;
-                j.sel_values = j.values; j.sel_n = j.n; j.sel_kind = j.kind;
-                if (j.passes == 0) {  // constant column
-                    const int64_t v = (int64_t)(j.min_b ^ SIGN);
-                    set_midpoint(j, v, v, false);
-                }
-            }
-        }
-    }
-    __syncthreads();
-    if (clear_hist)
-        for (uint32_t b = threadIdx.x; b < BINS; b += THREADS) hist[(size_t)a * BINS + b] = 0;
-}
-
-// ---- 4. radix select ---------------------------------------------------------------------
-
-// Digit `pass` of key into the workgroup's LDS histogram, if the key shares the resolved prefix.
-// (Letting the lanes of a wave that hold the same bin send one atomic between them, for columns of
-// a few distinct values, made the one-workgroup select slower on every column shape tried.)
-__device__ __forceinline__ void hist_key(uint32_t *lh, uint64_t key, uint32_t pass, uint32_t shift, uint64_t prefix, bool last,
-                                         uint64_t &above) {
-    if (pass == 0) {
-        atomicAdd(&lh[(uint32_t)(key >> shift)], 1u);
-    } else {
-        const uint64_t high = key >> (shift + DIGIT_BITS);
-        if (high == prefix) atomicAdd(&lh[(uint32_t)(key >> shift) & (BINS - 1)], 1u);
-        else if (last && high > prefix) above = min(above, key);
-    }
-}
-
-// One workgroup's share (tiles w, w + per_array, ...) of one array's histogram pass.
-__device__ __forceinline__ void hist_one(EncodeJob *__restrict__ jobs, uint32_t a, uint32_t w, uint32_t per_array, uint32_t tiles_per_wg,
-                                         uint32_t *__restrict__ hist, uint32_t pass, uint32_t *lh) {
-    const EncodeJob &job = jobs[a];
-    const uint32_t mode = job.mode;
-    if ((mode != SEL_FULL && mode != SEL_BRACKET_COMPACT) || pass >= job.passes) return;
-    // Every workgroup that takes part merges up to BINS counters into the array's histogram with
-    // device-scope atomics, which cost more than reading a tile: only as many workgroups take part
-    // as have tiles_per_wg tiles each (a candidate list holds job.inb values).
-    const uint64_t work_tiles = ((mode == SEL_FULL ? job.n : job.inb) + TILE - 1) / TILE;
-    if (tiles_per_wg == 0) tiles_per_wg = work_tiles >= 4096 ? 16u : work_tiles < 512 ? 2u : (uint32_t)(work_tiles / 256);
-    const uint64_t want = work_tiles / tiles_per_wg;
-    const uint32_t eff = want < 1 ? 1u : want < per_array ? (uint32_t)want : per_array;
-    if (w >= eff) return;
-    __syncthreads();  // the previous item's merge has read lh
-    for (uint32_t b = threadIdx.x; b < BINS; b += THREADS) lh[b] = 0;
-    __syncthreads();
-    const uint32_t shift = DIGIT_BITS * (job.passes - 1 - pass);
-    const bool last = pass + 1 == job.passes;
-    const uint64_t prefix = job.prefix, base = job.key_base;
-    uint64_t above = ~0ull;
-    if (mode == SEL_FULL) {
-        const void *values = job.values;
-        const uint32_t kind = job.kind;
-        const uint64_t n = job.n;
-        for (uint64_t v0 = (uint64_t)w * TILE; v0 < n; v0 += (uint64_t)eff * TILE) {
-            int64_t x[2 * PAIRS];
-            load_tile_from(values, kind, v0, n, 0, x);
-#pragma unroll
-            for (int e = 0; e < 2 * PAIRS; ++e) {
-                const uint64_t i = v0 + tile_slot(kind, e);
-                if (i < n) hist_key(lh, ((uint64_t)x[e] ^ SIGN) - base, pass, shift, prefix, last, above);
-            }
-        }
-    } else {
-        const uint64_t seg_cap = job.seg_cap, seg_tiles = seg_cap / TILE;
-        for (uint64_t u = w; u < seg_tiles * CAND_SEGS; u += eff) {
-            const uint64_t sgm = u % CAND_SEGS, v0 = sgm * seg_cap + (u / CAND_SEGS) * TILE;
-            const uint64_t end = sgm * seg_cap + job.counters->slot[sgm].cand_count;  // values exist below this index
-            if (v0 >= end) continue;
-            int64_t x[2 * PAIRS];
-            load_tile_from(job.cand, ZBRA_ELEM_I64, v0, end, 0, x);
-#pragma unroll
-            for (int e = 0; e < 2 * PAIRS; ++e) {
-                const uint64_t i = v0 + tile_slot(ZBRA_ELEM_I64, e);
-                if (i < end) hist_key(lh, ((uint64_t)x[e] ^ SIGN) - base, pass, shift, prefix, last, above);
-            }
-        }
-    }
-    __syncthreads();
-    uint32_t *gh = hist + (size_t)a * BINS;
-    for (uint32_t b = threadIdx.x; b < BINS; b += THREADS) {
-        const uint32_t c = lh[b];
-        if (c) atomicAdd(&gh[b], c);
-    }
-    if (last && pass > 0) {
-        above = wave_min_u64(above);
-        if ((threadIdx.x & 63) == 0 && above != ~0ull)
-            atomicMin((unsigned long long *)&jobs[a].next_above, (unsigned long long)above);
-    }
-}
-
-// Histogram of digit `pass` of the keys that share the resolved prefix, over what each array's
-// select reads: the whole array (tiles of TILE values) or its candidate list (segments, each
-// filled from its start).  `pending` = {count, arrays...} names the arrays that still need passes
-// (written by enc_select_small_kernel: the host cannot know).  The grid is fixed; its workgroups
-// are dealt evenly to the pending arrays, workgroup w of an array's `per_array` taking tiles w,
-// w + per_array, ..., so that an array is never left to the two or three workgroups that happen
-// to own its stretch of the submission.
-__global__ __launch_bounds__(THREADS) void enc_hist_kernel(EncodeJob *__restrict__ jobs, const uint32_t *__restrict__ pending,
-                                                            uint32_t *__restrict__ hist, uint32_t pass) {
-    const uint32_t n_list = pending[0];
-    if (n_list == 0) return;
-    const uint32_t *list = pending + 1;
-    uint32_t per_array = gridDim.x / n_list;
-    if (per_array == 0) per_array = 1;
-    // Tiles a workgroup reads before it merges its 4096 counters into the array's histogram
-    // (device-scope atomics).  One 2^27-value array with a wide bracket: a real pass takes 142 us at
-    // 1.5 tiles per workgroup (4096 workgroups), 62 us at 4, 44 us at 16, 115 us at 64; a thousand
-    // arrays keep all their workgroups busy at 4 and slow down beyond.  0 = by the array's length:
-    // about 256 workgroups, 2 to 16 tiles each.
-    const uint32_t tiles_per_wg = n_list <= 4 ? 0u : 4u;
-    __shared__ uint32_t lh[BINS];
-    for (uint64_t item = blockIdx.x; item < (uint64_t)n_list * per_array; item += gridDim.x)  // uniform
-        hist_one(jobs, list[item / per_array], (uint32_t)(item % per_array), per_array, tiles_per_wg, hist, pass, lh);
-}
-
 // The bin that holds rank k of a BINS-bin histogram, found by one workgroup of THREADS lanes: lane
 // t brings bins [t * SEL_PER, +SEL_PER).  Every lane gets the same answer.
 constexpr int SEL_PER = BINS / THREADS;  // 16 consecutive bins per thread
 struct BinPick {
     uint32_t bin, cnt;   // the bin of rank k and how many keys it holds
-    uint32_t next_bin;   // the next bin above it that holds a key (BINS if none); only when asked for
+    uint32_t next_bin;   // the next bin above it that holds a key (BINS if none)
     uint32_t pad;
     uint64_t before;     // keys in the bins below
 };
@@ -673,14 +557,14 @@ struct BinPickShared {
     uint64_t part[THREADS];
     BinPick pick;
 };
-__device__ __forceinline__ BinPick pick_bin(const uint32_t (&c)[SEL_PER], uint64_t k, bool want_next, BinPickShared *sh) {
+__device__ __forceinline__ BinPick pick_bin(const uint32_t (&c)[SEL_PER], uint64_t k, BinPickShared *sh) {
     const uint32_t tid = threadIdx.x;
     uint64_t sum = 0;
 #pragma unroll
     for (int i = 0; i < SEL_PER; i++) sum += c[i];
     __syncthreads();  // the previous use of `sh` is over
     sh->part[tid] = sum;
-    if (tid == 0) sh->pick.next_bin = BINS;
+    if (tid == 0) { sh->pick.next_bin = BINS; sh->pick.bin = 0; sh->pick.cnt = 0; sh->pick.before = 0; }
     __syncthreads();
     // exclusive prefix of the per-thread sums (256 entries: a serial scan by every thread's own
     // loop would be 256 LDS reads; a Hillis-Steele scan is 8 steps)
@@ -702,15 +586,13 @@ __device__ __forceinline__ BinPick pick_bin(const uint32_t (&c)[SEL_PER], uint64
         }
     }
     __syncthreads();
-    if (want_next) {
-        const uint32_t d = sh->pick.bin;
+    const uint32_t d = sh->pick.bin;
 #pragma unroll
-        for (int i = 0; i < SEL_PER; i++) {
-            const uint32_t b = tid * SEL_PER + i;
-            if (b > d && c[i]) { atomicMin(&sh->pick.next_bin, b); break; }
-        }
-        __syncthreads();
+    for (int i = 0; i < SEL_PER; i++) {
+        const uint32_t b = tid * SEL_PER + i;
+        if (b > d && c[i]) { atomicMin(&sh->pick.next_bin, b); break; }
     }
+    __syncthreads();
     return sh->pick;
 }
 
@@ -721,40 +603,325 @@ __device__ __forceinline__ void finish_select(EncodeJob &job, uint64_t key_a, ui
     set_midpoint(job, va, vb, (job.n & 1) == 0);
 }
 
-// One workgroup per pending array: finds the bin that holds rank k, descends, and on the last
-// pass derives a, b and the midpoint.  Leaves the array's histogram zeroed for the next pass.
-__global__ __launch_bounds__(THREADS) void enc_select_kernel(EncodeJob *__restrict__ jobs, const uint32_t *__restrict__ pending,
-                                                              uint32_t *__restrict__ hist, uint32_t pass) {
-    if (blockIdx.x >= pending[0]) return;
-    const uint32_t a = pending[1 + blockIdx.x];
-    EncodeJob &job = jobs[a];
-    if (pass >= job.passes) return;
-    __shared__ BinPickShared sh;
-    uint32_t *gh = hist + (size_t)a * BINS;
-    const uint32_t tid = threadIdx.x;
+// State s says digit s.lv of the keys that share s.prefix is counted in `gh`: picks the bin of rank
+// s.k and descends into it.  By the whole workgroup; every lane gets the same state.
+// `next_key` = the smallest key above the picked bin as far as this histogram knows it: meaningful
+// only when this was the key's last digit (then a bin is one key), ~0 if no higher bin holds a key.
+__device__ __forceinline__ EncodeJob::SelState descend(EncodeJob::SelState s, const uint32_t *gh, BinPickShared *sh, uint64_t *next_key) {
     uint32_t c[SEL_PER];
 #pragma unroll
-    for (int i = 0; i < SEL_PER; i++) { c[i] = gh[tid * SEL_PER + i]; gh[tid * SEL_PER + i] = 0; }
-    const bool last = pass + 1 == job.passes;
-    const BinPick pk = pick_bin(c, job.k, last, &sh);
-    if (tid == 0) {
-        const uint64_t high = job.prefix;
-        const uint64_t key_a = pass == 0 ? (uint64_t)pk.bin : (high << DIGIT_BITS) | pk.bin;
-        const uint64_t k_in = job.k - pk.before;
-        job.prefix = key_a;
-        job.k = k_in;
-        if (last) {
-            uint64_t key_b = key_a;
-            if ((job.n & 1) == 0 && k_in + 1 >= pk.cnt) {
-                if (pk.next_bin < (uint32_t)BINS) key_b = pass == 0 ? (uint64_t)pk.next_bin : (high << DIGIT_BITS) | pk.next_bin;
-                else key_b = job.next_above;
+    for (int i = 0; i < SEL_PER; i++) c[i] = gh[threadIdx.x * SEL_PER + i];
+    const BinPick pk = pick_bin(c, s.k, sh);
+    const uint64_t high = s.lv == 0 ? 0 : s.prefix << DIGIT_BITS;
+    *next_key = pk.next_bin < (uint32_t)BINS ? (high | pk.next_bin) : ~0ull;
+    s.prefix = high | pk.bin;
+    s.k -= pk.before;
+    s.cnt = pk.cnt;
+    s.lv += 1;
+    s.action = ACT_NONE;
+    return s;
+}
+
+// Every digit of the key of a is resolved (s.lv == passes): a = s.prefix, and b, for an even
+// count, is the same key (multiplicity), the next key of the last histogram, or the smallest key
+// above everything that shared the earlier digits.  One lane.
+__device__ __forceinline__ void finish_digits(EncodeJob &job, const EncodeJob::SelState &s, uint64_t next_key) {
+    uint64_t key_b = s.prefix;
+    if ((job.n & 1) == 0 && s.k + 1 >= s.cnt) {
+        key_b = next_key;
+        if (key_b == ~0ull) key_b = (uint64_t)job.above_key < job.next_above ? (uint64_t)job.above_key : job.next_above;
+    }
+    finish_select(job, s.prefix, key_b);
+}
+
+// The s.cnt keys that share s.prefix are all `key` (the level that counted their next digit saw
+// min == max): a = key, and b is the same key or the smallest key above the run.  One lane.
+__device__ __forceinline__ void finish_run(EncodeJob &job, const EncodeJob::SelState &s, uint64_t key) {
+    uint64_t key_b = key;
+    if ((job.n & 1) == 0 && s.k + 1 >= s.cnt) key_b = (uint64_t)job.above_key < job.next_above ? (uint64_t)job.above_key : job.next_above;
+    finish_select(job, key, key_b);
+}
+
+// One workgroup per array.  Arrays whose select has more than `small_max` keys to read (and that
+// are long enough for that: a list holds at most n / CAND_DIV values) are put on the `pending`
+// list ({count, arrays...}, zero on entry) of the many-workgroup levels: one workgroup reads at
+// about 11 GB/s, so a long source is better spread over many.  Everything else is left to the one
+// workgroup per array of enc_finish_select_kernel.
+__global__ __launch_bounds__(THREADS) void enc_setup_kernel(EncodeJob *__restrict__ jobs, uint32_t nd,
+                                                             uint32_t *__restrict__ pending, uint64_t small_max) {
+    const uint32_t a = blockIdx.x;
+    if (a >= nd) return;
+    EncodeJob &j = jobs[a];
+    __shared__ EncodeJob::SelState s0;
+    __shared__ uint64_t src_n;
+    __shared__ BinPickShared sh;
+    if (threadIdx.x == 0) {
+        s0.prefix = 0; s0.k = 0; s0.cnt = 0; s0.lv = 0; s0.action = ACT_DONE;
+        src_n = 0;
+        if (j.n == 0) {
+            j.passes = 0;
+        } else if (j.kind == KIND_U64_PLAIN) {
+            j.passes = 0; j.need_or = 1; j.midpoint = 0;
+        } else if (j.mode != SEL_DONE) {
+            const uint64_t span = j.max_b - j.min_b;
+            j.need_or = span >= SIGN;
+            const uint64_t k = (j.n - 1) / 2;  // rank of a: n/2 - 1 for even n, n/2 for odd n
+            bool whole_list = true;
+            if (j.mode != SEL_FULL) {
+                j.below = 0; j.inb = 0;
+                for (int sgm = 0; sgm < CAND_SEGS; sgm++) {
+                    j.below += j.counters->slot[sgm].below;
+                    j.inb += j.counters->slot[sgm].inb;
+                    whole_list = whole_list && j.counters->slot[sgm].cand_count <= j.seg_cap;
+                }
             }
-            finish_select(job, key_a, key_b);
+            // Rank k must fall inside the bracket (rank k+1, for even n, may also be the smallest
+            // value above it).  The bracket pass has then counted the first digit of the keys inside
+            // it (every digit there is, for a narrow bracket), whether or not the candidate list is
+            // whole.
+            const bool ok = j.mode != SEL_FULL && k >= j.below && k < j.below + j.inb;
+            if (ok) {
+                // key_base = lo_b and passes were set with the bracket, by the sample kernel
+                if (j.next_above != ~0ull) j.next_above -= j.key_base;  // into key space
+                s0.k = k - j.below; s0.cnt = j.inb; s0.action = ACT_HIST;
+                j.flo = j.lo_b; j.fhi = j.hi_b;
+                if (j.mode == SEL_BRACKET_HIST) {
+                    src_n = 0;  // nothing left to read
+                } else if (whole_list) {
+                    src_n = j.inb;
+                } else {  // more than n / CAND_DIV values inside a wide bracket: the select reads the array itself
+                    j.mode = SEL_FULL;
+                    src_n = j.n;
+                }
+            } else {
+                j.mode = SEL_FULL;
+                j.key_base = j.min_b;
+                j.next_above = ~0ull;
+                j.passes = (bit_length64(span) + DIGIT_BITS - 1) / DIGIT_BITS;
+                j.flo = 0; j.fhi = ~0ull;
+                s0.k = k; s0.cnt = j.n; s0.action = ACT_NONE;
+                src_n = j.n;
+                if (j.passes == 0) {  // constant column
+                    const int64_t v = (int64_t)(j.min_b ^ SIGN);
+                    set_midpoint(j, v, v, false);
+                    s0.action = ACT_DONE;
+                }
+            }
+        }
+    }
+    __syncthreads();
+    EncodeJob::SelState s = s0;
+    if (s.action == ACT_HIST) {
+        // the first digit is counted: pick its bin here, once, rather than in every workgroup of
+        // the first level; a narrow bracket is finished by this
+        uint64_t next_key = ~0ull;
+        s = descend(s, j.hist, &sh, &next_key);
+        if (threadIdx.x == 0 && s.lv == j.passes) {
+            finish_digits(j, s, next_key);
+            s.action = ACT_DONE;
+        }
+        if (s.lv == j.passes) s.action = ACT_DONE;
+    }
+    if (threadIdx.x == 0) {
+        j.S[0] = s;
+        // A candidate list holds at most n / CAND_DIV values, so an array of up to CAND_DIV *
+        // small_max values can only exceed small_max by reading all its values; those stay with
+        // the one workgroup too, which lets the host skip the many-workgroup levels for a
+        // submission without longer arrays.
+        if (s.action != ACT_DONE && src_n > small_max && j.n > (uint64_t)CAND_DIV * small_max && j.lvl_hist) {
+            j.pending = 1;
+            pending[1 + atomicAdd(&pending[0], 1u)] = a;
         }
     }
 }
 
-// ---- 4b. short select sources: one workgroup per array, every pass in one launch ---------------
+// ---- 4. radix select ---------------------------------------------------------------------
+
+// Keys that share s.prefix (s.lv digits resolved) in a key of `passes` digits.
+__device__ __forceinline__ bool shares_prefix(uint64_t key, const EncodeJob::SelState &s, uint32_t passes) {
+    return s.lv == 0 || (key >> (DIGIT_BITS * (passes - s.lv))) == s.prefix;
+}
+__device__ __forceinline__ bool above_prefix(uint64_t key, const EncodeJob::SelState &s, uint32_t passes) {
+    return s.lv != 0 && (key >> (DIGIT_BITS * (passes - s.lv))) > s.prefix;
+}
+
+// ---- 4a. long select sources: up to SEL_LEVELS launches of many workgroups ----------------------
+//
+// Level L (1..SEL_LEVELS), for every pending array: every workgroup that takes part first brings the
+// array's state up to date by itself (if the launch before counted a digit, it picks the bin of
+// rank k from that histogram: 16 KiB read, one scan; all workgroups get the same answer, the first
+// one records it as S[L]), then
+//   - if every digit is resolved, the first workgroup derives the midpoint;
+//   - if at most GATHER_CAP keys share the resolved digits, the workgroups gather them (and the
+//     smallest key above them) for the finishing workgroup to sort;
+//   - else they count the next digit of the keys that share the resolved digits.
+// No workgroup waits for another one: kernel boundaries are the only ordering.
+
+// One workgroup's share (tiles w, w + eff, ...) of one array at level L.
+__device__ __forceinline__ void level_one(EncodeJob *__restrict__ jobs, uint32_t a, uint32_t w, uint32_t per_array, uint32_t tiles_per_wg,
+                                          uint32_t L, uint32_t *lh, BinPickShared *sh) {
+    EncodeJob &job = jobs[a];
+    const uint32_t tid = threadIdx.x;
+    const EncodeJob::SelState s0 = job.S[L - 1];
+    if (s0.action == ACT_DONE || s0.action == ACT_GATHER) {  // finished, or waiting for the finishing workgroup
+        if (w == 0 && tid == 0) job.S[L] = s0;
+        return;
+    }
+    // Every workgroup that counts merges up to BINS counters into the array's histogram with
+    // device-scope atomics, which cost more than reading a tile: only as many workgroups take part
+    // as have tiles_per_wg tiles each.
+    const bool from_list = job.mode == SEL_BRACKET_COMPACT;
+    const uint64_t work_tiles = ((from_list ? job.inb : job.n) + TILE - 1) / TILE;
+    // A digit counted among keys that share earlier digits, and a gather, touch few counters:
+    // nothing to merge, so every workgroup is worth having.
+    const bool sparse = s0.action == ACT_HIST || s0.lv > 0;
+    if (sparse) tiles_per_wg = tiles_per_wg == 0 ? 8u : 2u;  // few arrays / many (measured: 1, 2, 4, 8, 16 tiles)
+    else if (tiles_per_wg == 0) tiles_per_wg = work_tiles >= 4096 ? 16u : work_tiles < 512 ? 2u : (uint32_t)(work_tiles / 256);
+    const uint64_t want = work_tiles / tiles_per_wg;
+    const uint32_t eff = want < 1 ? 1u : want < per_array ? (uint32_t)want : per_array;
+    if (w >= eff) return;
+    const uint32_t passes = job.passes;
+    EncodeJob::SelState s = s0;
+    uint64_t next_key = ~0ull;
+    if (s0.action == ACT_HIST && L >= 2 && s0.lv > 0 && job.match_min[L - 2] == job.match_max[L - 2]) {
+        // the level before counted a digit of keys that are all the same: nothing left to resolve
+        if (w == 0 && tid == 0) {
+            finish_run(job, s0, job.match_min[L - 2]);
+            s.action = ACT_DONE;
+            job.S[L] = s;
+        }
+        return;
+    }
+    if (s0.action == ACT_HIST) s = descend(s0, L == 1 ? job.hist : job.lvl_hist + (size_t)(L - 2) * BINS, sh, &next_key);
+    if (s.lv == passes) {
+        if (w == 0 && tid == 0) {
+            finish_digits(job, s, next_key);
+            s.action = ACT_DONE;
+            job.S[L] = s;
+        }
+        return;
+    }
+    const bool gather = s.cnt <= (uint64_t)GATHER_CAP;
+    if (w == 0 && tid == 0) {
+        s.action = gather ? ACT_GATHER : ACT_HIST;
+        job.S[L] = s;
+    }
+    // LDS: the digit's histogram, or the keys this workgroup gathers (at most GATHER_CAP in all)
+    static_assert(GATHER_CAP * sizeof(uint64_t) <= BINS * sizeof(uint32_t), "gathered keys are staged in the histogram's LDS");
+    uint64_t *stage = (uint64_t *)lh;
+    __shared__ uint32_t stage_n, stage_base;
+    __syncthreads();  // the previous item's merge, and this item's pick, have read LDS
+    if (gather) { if (tid == 0) stage_n = 0; }
+    else for (uint32_t b = tid; b < BINS; b += THREADS) lh[b] = 0;
+    __syncthreads();
+    const uint32_t shift = DIGIT_BITS * (passes - 1 - s.lv);  // of the digit to count
+    const uint64_t base = job.key_base;
+    // `above`: the smallest key above the keys that share the resolved digits.  It is what b falls
+    // back on when this turns out to be the array's last read (a gather, the last digit, a run of
+    // one value); a later level's set of such keys contains this one's, so one running minimum
+    // per array serves them all.
+    uint64_t above = ~0ull, kmin = ~0ull, kmax = 0;
+    auto visit = [&](uint64_t key) {
+        if (shares_prefix(key, s, passes)) {
+            if (gather) {
+                const uint32_t slot = atomicAdd(&stage_n, 1u);
+                if (slot < GATHER_CAP) stage[slot] = key;  // always true while nobody writes the source: s.cnt keys in all
+            } else {
+                atomicAdd(&lh[(uint32_t)(key >> shift) & (BINS - 1)], 1u);
+                kmin = min(kmin, key);
+                kmax = max(kmax, key);
+            }
+        } else if (above_prefix(key, s, passes)) {
+            above = min(above, key);
+        }
+    };
+    if (!from_list) {
+        const void *values = job.values;
+        const uint32_t kind = job.kind;
+        const uint64_t n = job.n, flo = job.flo, fhi = job.fhi;
+        for (uint64_t v0 = (uint64_t)w * TILE; v0 < n; v0 += (uint64_t)eff * TILE) {
+            int64_t x[2 * PAIRS];
+            load_tile_from(values, kind, v0, n, 0, x);
+#pragma unroll
+            for (int e = 0; e < 2 * PAIRS; ++e) {
+                const uint64_t i = v0 + tile_slot(kind, e);
+                const uint64_t b = (uint64_t)x[e] ^ SIGN;
+                if (i < n && b >= flo && b <= fhi) visit(b - base);
+            }
+        }
+    } else {
+        const uint64_t seg_cap = job.seg_cap, seg_tiles = seg_cap / TILE;
+        for (uint64_t u = w; u < seg_tiles * CAND_SEGS; u += eff) {
+            const uint64_t sgm = u % CAND_SEGS, v0 = sgm * seg_cap + (u / CAND_SEGS) * TILE;
+            const uint64_t end = sgm * seg_cap + job.counters->slot[sgm].cand_count;  // values exist below this index
+            if (v0 >= end) continue;
+            int64_t x[2 * PAIRS];
+            load_tile_from(job.cand, ZBRA_ELEM_I64, v0, end, 0, x);
+#pragma unroll
+            for (int e = 0; e < 2 * PAIRS; ++e) {
+                const uint64_t i = v0 + tile_slot(ZBRA_ELEM_I64, e);
+                if (i < end) visit(((uint64_t)x[e] ^ SIGN) - base);
+            }
+        }
+    }
+    __syncthreads();
+    if (gather) {
+        const uint32_t cnt = stage_n < GATHER_CAP ? stage_n : GATHER_CAP;
+        if (tid == 0 && cnt) stage_base = atomicAdd(&job.small_n, cnt);
+        __syncthreads();
+        if (cnt) {
+            const uint32_t at = stage_base;
+            for (uint32_t i = tid; i < cnt; i += THREADS)
+                if (at + i < GATHER_CAP) job.small[at + i] = stage[i];  // always true while nobody writes the source
+        }
+    } else {
+        uint32_t *gh = job.lvl_hist + (size_t)(L - 1) * BINS;
+        for (uint32_t b = tid; b < BINS; b += THREADS) {
+            const uint32_t c = lh[b];
+            if (c) atomicAdd(&gh[b], c);
+        }
+    }
+    // Thousands of waves hold a key above the prefix and all would queue on one word: look first
+    // (a stale look only costs an atomic that changes nothing; the minimum settles after a few).
+    above = wave_min_u64(above);
+    if ((tid & 63) == 0 && above < __hip_atomic_load(&job.above_key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+        atomicMin(&job.above_key, (unsigned long long)above);
+    if (!gather) {
+        kmin = wave_min_u64(kmin);
+        kmax = wave_max_u64(kmax);
+        if ((tid & 63) == 0 && kmin <= kmax) {
+            if (kmin < __hip_atomic_load(&job.match_min[L - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+                atomicMin(&job.match_min[L - 1], (unsigned long long)kmin);
+            if (kmax > __hip_atomic_load(&job.match_max[L - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+                atomicMax(&job.match_max[L - 1], (unsigned long long)kmax);
+        }
+    }
+}
+
+// `pending` = {count, arrays...}, written by enc_setup_kernel (the host cannot know it).  The grid
+// is fixed; its workgroups are dealt evenly to the pending arrays, workgroup w of an array's
+// `per_array` taking tiles w, w + per_array, ..., so that an array is never left to the two or
+// three workgroups that happen to own its stretch of the submission.  With nothing pending the
+// launch ends at its first load.
+__global__ __launch_bounds__(THREADS) void enc_level_kernel(EncodeJob *__restrict__ jobs, const uint32_t *__restrict__ pending, uint32_t L) {
+    const uint32_t n_list = pending[0];
+    if (n_list == 0) return;
+    const uint32_t *list = pending + 1;
+    uint32_t per_array = gridDim.x / n_list;
+    if (per_array == 0) per_array = 1;
+    // Tiles a workgroup reads before it merges its 4096 counters into the array's histogram
+    // (device-scope atomics).  One 2^27-value array with a wide bracket: a counting pass takes
+    // 142 us at 1.5 tiles per workgroup (4096 workgroups), 62 us at 4, 44 us at 16, 115 us at 64; a
+    // thousand arrays keep all their workgroups busy at 4 and slow down beyond.  0 = by the array's
+    // length: about 256 workgroups, 2 to 16 tiles each.
+    const uint32_t tiles_per_wg = n_list <= 4 ? 0u : 4u;
+    __shared__ uint32_t lh[BINS];
+    __shared__ BinPickShared sh;
+    for (uint64_t item = blockIdx.x; item < (uint64_t)n_list * per_array; item += gridDim.x)  // uniform
+        level_one(jobs, list[item / per_array], (uint32_t)(item % per_array), per_array, tiles_per_wg, L, lh, &sh);
+}
+
+// ---- 4b. the finishing workgroup: one per array, every remaining digit in one launch -------------
 
 // f(key) for every key of what the array's select reads, by the whole workgroup.  One workgroup
 // reading tile after tile would pay a full memory latency per tile, so four tiles (of the array,
@@ -768,7 +935,7 @@ __device__ __forceinline__ void for_each_select_key(const EncodeJob &job, uint32
     if (mode == SEL_FULL) {
         const void *values = job.values;
         const uint32_t kind = job.kind;
-        const uint64_t n = job.n;
+        const uint64_t n = job.n, flo = job.flo, fhi = job.fhi;
         for (uint64_t v0 = 0; v0 < n; v0 += (uint64_t)SEL_AHEAD * TILE) {
 #pragma unroll
             for (int u = 0; u < SEL_AHEAD; u++)
@@ -778,8 +945,10 @@ __device__ __forceinline__ void for_each_select_key(const EncodeJob &job, uint32
                 const uint64_t t0 = v0 + (uint64_t)u * TILE;
                 if (t0 < n) {
 #pragma unroll
-                    for (int e = 0; e < 2 * PAIRS; ++e)
-                        if (t0 + tile_slot(kind, e) < n) f(((uint64_t)x[u][e] ^ SIGN) - base);
+                    for (int e = 0; e < 2 * PAIRS; ++e) {
+                        const uint64_t b = (uint64_t)x[u][e] ^ SIGN;
+                        if (t0 + tile_slot(kind, e) < n && b >= flo && b <= fhi) f(b - base);
+                    }
                 }
             }
         }
@@ -808,35 +977,26 @@ __device__ __forceinline__ void for_each_select_key(const EncodeJob &job, uint32
     }
 }
 
-// Arrays whose select reads at most `small_max` keys (a short candidate list, a short array, or
-// nothing at all when the bracket pass already filled the histogram) are finished here by one
-// workgroup each: histogram in LDS, no device-scope atomic, and after the first digit the keys
-// that share it are usually a handful: as soon as KEEP or fewer are left they are gathered into
-// LDS and sorted, so the source is read twice, not once per digit.  Arrays with a longer source
-// are put on the `pending` list ({count, arrays...}, zero on entry) of the pass-per-launch kernels,
-// untouched: one workgroup reads at about 11 GB/s, so a long list is better spread over many.
-// Measured thresholds (2^12 .. 2^19 keys): a thousand 2^20-row arrays encode in 4.73-4.85 ms
-// whatever it is; 1152 ragged columns of up to 2^21 rows 6.31 ms up to 2^14 against 6.55 ms at
-// 2^19; 96 columns of 2^22 rows 2.37 against 2.54 ms.
+// One workgroup per listed array finishes its select, from wherever the earlier launches left it:
+//   - the bracket pass counted every digit there is (narrow bracket): one pick;
+//   - a level gathered the keys that share the resolved digits: they are sorted in LDS;
+//   - otherwise the workgroup reads the source itself, digit by digit (histogram in LDS, no
+//     device-scope atomic), and as soon as KEEP or fewer keys share the resolved digits it gathers
+//     and sorts them, so a short source is read twice, not once per digit.  This is also the
+//     (slow, exact) way out for a long source that SEL_LEVELS levels did not resolve: more than
+//     GATHER_CAP different keys of one array inside 2^-36 of its bracket.
+// Measured thresholds for "short" (2^12 .. 2^19 keys): a thousand 2^20-row arrays encode in
+// 4.73-4.85 ms whatever it is; 1152 ragged columns of up to 2^21 rows 6.31 ms up to 2^14 against
+// 6.55 ms at 2^19; 96 columns of 2^22 rows 2.37 against 2.54 ms.
 constexpr uint64_t SMALL_SRC_MAX = 1ull << 14;  // default of the `small_max` argument
-constexpr uint32_t KEEP = 2048;  // 16 KiB: with the histogram and the scan, four workgroups fit a CU
-__global__ __launch_bounds__(THREADS) void enc_select_small_kernel(EncodeJob *__restrict__ jobs, const uint32_t *__restrict__ list,
-                                                                    uint32_t n_list, uint32_t *__restrict__ hist,
-                                                                    uint32_t *__restrict__ pending, uint64_t small_max) {
+constexpr uint32_t KEEP = GATHER_CAP;  // 16 KiB: with the histogram and the scan, four workgroups fit a CU
+__global__ __launch_bounds__(THREADS) void enc_finish_select_kernel(EncodeJob *__restrict__ jobs, const uint32_t *__restrict__ list,
+                                                                     uint32_t n_list) {
     if (blockIdx.x >= n_list) return;
     const uint32_t a = list[blockIdx.x];
     EncodeJob &job = jobs[a];
     const uint32_t passes = job.passes, mode = job.mode;
     if (passes == 0 || mode == SEL_DONE) return;
-    const uint64_t src_n = mode == SEL_FULL ? job.n : mode == SEL_BRACKET_COMPACT ? job.inb : 0;
-    // A candidate list holds at most n / CAND_DIV values, so an array of up to CAND_DIV * small_max
-    // values can only exceed small_max by reading all its values (no list, or a bracket that
-    // missed); those stay here too, which lets the host skip the pass-per-launch kernels for a
-    // submission without longer arrays (a 2^16-value array: 7 launches instead of 19).
-    if (src_n > small_max && job.n > (uint64_t)CAND_DIV * small_max) {  // too long for one workgroup
-        if (threadIdx.x == 0) pending[1 + atomicAdd(&pending[0], 1u)] = a;
-        return;
-    }
     __shared__ uint32_t lh[BINS];
     __shared__ uint64_t keep[KEEP];
     __shared__ BinPickShared sh;
@@ -844,76 +1004,89 @@ __global__ __launch_bounds__(THREADS) void enc_select_small_kernel(EncodeJob *__
     __shared__ unsigned long long above_all;
     const uint32_t tid = threadIdx.x;
     const bool even = (job.n & 1) == 0;
-    uint64_t prefix = 0, k = job.k;
-    for (uint32_t pass = 0; pass < passes; ++pass) {  // uniform
-        const uint32_t shift = DIGIT_BITS * (passes - 1 - pass);
-        const bool last = pass + 1 == passes;
-        uint64_t above = ~0ull;
-        if (mode == SEL_BRACKET_HIST) {  // one pass, histogram already counted
-            uint32_t *gh = hist + (size_t)a * BINS;
-            for (uint32_t b = tid; b < (uint32_t)BINS; b += THREADS) { lh[b] = gh[b]; gh[b] = 0; }
-        } else {
-            for (uint32_t b = tid; b < (uint32_t)BINS; b += THREADS) lh[b] = 0;
-            __syncthreads();
-            for_each_select_key(job, mode, [&](uint64_t key) { hist_key(lh, key, pass, shift, prefix, last, above); });
-        }
-        if (tid == 0) above_all = ~0ull;
+    const uint32_t at = job.pending ? (uint32_t)SEL_LEVELS : 0u;  // the last state written
+    EncodeJob::SelState s = job.S[at];
+    if (s.action == ACT_DONE) return;
+    if (tid == 0) above_all = ~0ull;
+    uint64_t next_key = ~0ull;
+    if (s.action == ACT_HIST && at > 0 && s.lv > 0 && job.match_min[at - 1] == job.match_max[at - 1]) {
+        if (tid == 0) finish_run(job, s, job.match_min[at - 1]);  // the last level counted a digit of keys that are all the same
+        return;
+    }
+    if (s.action == ACT_HIST) s = descend(s, at == 0 ? job.hist : job.lvl_hist + (size_t)(at - 1) * BINS, &sh, &next_key);
+    // the smallest key above the keys that share the resolved digits, as far as earlier launches know
+    auto above_so_far = [&]() -> uint64_t {
+        const uint64_t x = (uint64_t)job.above_key < job.next_above ? (uint64_t)job.above_key : job.next_above;
+        return (uint64_t)above_all < x ? (uint64_t)above_all : x;
+    };
+    // sorts keep[0, cnt) and reads a and b off it
+    auto finish_sorted = [&](uint32_t cnt) {
+        uint32_t m = 2;
+        while (m < cnt) m <<= 1;
         __syncthreads();
-        uint32_t c[SEL_PER];
-#pragma unroll
-        for (int i = 0; i < SEL_PER; i++) c[i] = lh[tid * SEL_PER + i];
-        const BinPick pk = pick_bin(c, k, last, &sh);
-        const uint64_t high = prefix;
-        prefix = pass == 0 ? (uint64_t)pk.bin : (high << DIGIT_BITS) | pk.bin;
-        k -= pk.before;
-        if (last) {
-            above = wave_min_u64(above);
-            if ((tid & 63) == 0 && above != ~0ull) atomicMin(&above_all, (unsigned long long)above);
+        for (uint32_t i = cnt + tid; i < m; i += THREADS) keep[i] = ~0ull;  // padding sorts to the end
+        sort_keys_lds<THREADS>(keep, m);
+        if (tid == 0) {
+            const uint64_t key_a = keep[s.k];
+            uint64_t key_b = key_a;
+            if (even) key_b = s.k + 1 < cnt ? keep[s.k + 1] : above_so_far();
+            finish_select(job, key_a, key_b);
+        }
+    };
+    if (s.action == ACT_GATHER) {  // a level left the keys in `small`
+        const uint32_t cnt = (uint32_t)s.cnt;  // == job.small_n
+        for (uint32_t i = tid; i < cnt; i += THREADS) keep[i] = job.small[i];
+        finish_sorted(cnt);
+        return;
+    }
+    while (true) {  // uniform
+        if (s.lv == passes) {
+            // a wide last digit's `above` (keys above the earlier digits) was collected with its histogram
             __syncthreads();
             if (tid == 0) {
-                uint64_t key_b = prefix;
-                if (even && k + 1 >= pk.cnt) {
-                    if (pk.next_bin < (uint32_t)BINS) key_b = pass == 0 ? (uint64_t)pk.next_bin : (high << DIGIT_BITS) | pk.next_bin;
-                    else key_b = above_all < job.next_above ? (uint64_t)above_all : job.next_above;
-                }
-                finish_select(job, prefix, key_b);
-                job.passes = 0;
+                if (next_key == ~0ull) next_key = above_so_far();
+                uint64_t key_b = s.prefix;
+                if (even && s.k + 1 >= s.cnt) key_b = next_key;
+                finish_select(job, s.prefix, key_b);
             }
             return;
         }
-        if (pk.cnt <= KEEP) {
+        if (s.cnt <= (uint64_t)KEEP) {
             // gather the keys that share the resolved digits, sort them, read a and b off the list
             if (tid == 0) keep_n = 0;
             __syncthreads();
-            above = ~0ull;
+            uint64_t above = ~0ull;
             for_each_select_key(job, mode, [&](uint64_t key) {
-                const uint64_t h = key >> shift;
-                if (h == prefix) {
-                    const uint32_t at = atomicAdd(&keep_n, 1u);
-                    if (at < KEEP) keep[at] = key;  // always true while nobody writes the source
+                if (shares_prefix(key, s, passes)) {
+                    const uint32_t slot = atomicAdd(&keep_n, 1u);
+                    if (slot < KEEP) keep[slot] = key;  // always true while nobody writes the source
+                } else if (above_prefix(key, s, passes)) {
+                    above = min(above, key);
                 }
-                else if (h > prefix) above = min(above, key);
             });
             above = wave_min_u64(above);
             if ((tid & 63) == 0 && above != ~0ull) atomicMin(&above_all, (unsigned long long)above);
-            __syncthreads();
-            const uint32_t cnt = pk.cnt;  // == keep_n
-            uint32_t m = 2;
-            while (m < cnt) m <<= 1;
-            for (uint32_t i = cnt + tid; i < m; i += THREADS) keep[i] = ~0ull;  // padding sorts to the end
-            sort_keys_lds<THREADS>(keep, m);
-            if (tid == 0) {
-                const uint64_t key_a = keep[k];
-                uint64_t key_b = key_a;
-                if (even) {
-                    if (k + 1 < cnt) key_b = keep[k + 1];
-                    else key_b = above_all < job.next_above ? (uint64_t)above_all : job.next_above;
-                }
-                finish_select(job, key_a, key_b);
-                job.passes = 0;
-            }
+            finish_sorted((uint32_t)s.cnt);  // == keep_n
             return;
         }
+        // count the next digit of the keys that share the resolved ones
+        const uint32_t shift = DIGIT_BITS * (passes - 1 - s.lv);
+        const bool last_digit = s.lv + 1 == passes;
+        __syncthreads();
+        for (uint32_t b = tid; b < (uint32_t)BINS; b += THREADS) lh[b] = 0;
+        __syncthreads();
+        uint64_t above = ~0ull;
+        for_each_select_key(job, mode, [&](uint64_t key) {
+            if (shares_prefix(key, s, passes)) atomicAdd(&lh[(uint32_t)(key >> shift) & (BINS - 1)], 1u);
+            else if (last_digit && above_prefix(key, s, passes)) above = min(above, key);
+        });
+        if (last_digit) {
+            above = wave_min_u64(above);
+            if ((tid & 63) == 0 && above != ~0ull) atomicMin(&above_all, (unsigned long long)above);
+        }
+        __syncthreads();
+        s.action = ACT_HIST;
+        s = descend(s, lh, &sh, &next_key);
     }
 }
 
