@@ -11,8 +11,10 @@ d=$(mktemp -d /tmp/prof.XXXXXX)
 export TMPDIR=/tmp
 cd /tmp
 timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d "$d/t" -o t -- python3 "$root/scripts/enc_width_prof.py" "$bits" 27 10 2>/dev/null | tail -1 > "$out"
+if [ -z "$FAST" ]; then  # FAST=1: kernel times only
 timeout -s KILL 120 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$d/f" -o f -- python3 "$root/scripts/enc_width_prof.py" "$bits" 27 2 > /dev/null 2>&1
 timeout -s KILL 120 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$d/w" -o w -- python3 "$root/scripts/enc_width_prof.py" "$bits" 27 2 > /dev/null 2>&1
+fi
 python3 - "$d" "$bits" >> "$out" <<'PY'
 import csv, glob, re, sys
 from collections import defaultdict
@@ -25,6 +27,8 @@ for r in csv.DictReader(open(glob.glob(d + "/t/**/*kernel_stats.csv", recursive=
         times[short(r["Name"])] = (int(r["Calls"]), float(r["AverageNs"]) / 1000)
 def pmc(sub):
     per = defaultdict(list)
+    if not glob.glob(d + f"/{sub}/**/*counter_collection.csv", recursive=True):
+        return per
     for r in csv.DictReader(open(glob.glob(d + f"/{sub}/**/*counter_collection.csv", recursive=True)[0])):
         if "zbra" in r["Kernel_Name"]:
             per[short(r["Kernel_Name"])].append(float(r["Counter_Value"]) * 1024)   # KiB -> B

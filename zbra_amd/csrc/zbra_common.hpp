@@ -66,6 +66,13 @@ __device__ __forceinline__ uint64_t zigzag_encode64(int64_t n) {
     return ((uint64_t)n << 1) ^ (uint64_t)(n >> 63);
 }
 
+// The 16 bytes that start 4*Q + r bytes into the 32 bytes a[0..8) (r = 0..3), as four dwords.
+template <int Q>
+__device__ __forceinline__ void funnel_bytes(const uint32_t (&a)[8], uint32_t r, uint32_t (&o)[4]) {
+#pragma unroll
+    for (int k = 0; k < 4; k++) o[k] = __builtin_amdgcn_alignbyte(a[Q + k + 1], a[Q + k], r);
+}
+
 // First array whose tile range contains tile t: largest a with tile_start[a] <= t.
 // tile_start has nd + 1 entries; every lane of the workgroup computes the same answer.
 __device__ __forceinline__ uint32_t find_array(const uint64_t *__restrict__ tile_start, uint32_t nd, uint64_t t) {

@@ -123,12 +123,6 @@ __device__ __forceinline__ uint32_t extract_bits(const uint32_t *lds, uint32_t b
 // 32-bit zig-zag decode; exact for inputs below 2^31 (w <= 31).
 __device__ __forceinline__ int32_t zigzag_decode32(uint32_t z) { return (int32_t)(z >> 1) ^ -(int32_t)(z & 1u); }
 
-template <int Q>
-__device__ __forceinline__ void funnel_bytes(const uint32_t (&a)[8], uint32_t r, uint32_t (&o)[4]) {
-#pragma unroll
-    for (int k = 0; k < 4; k++) o[k] = __builtin_amdgcn_alignbyte(a[Q + k + 1], a[Q + k], r);
-}
-
 template <int NT>
 __device__ __forceinline__ void store_pair_i64(ZBRA_GLOBAL int64_t *out, uint32_t j, uint32_t nv, int64_t o0, int64_t o1) {
     if (j + 1 < nv) {

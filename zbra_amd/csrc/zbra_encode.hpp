@@ -46,7 +46,7 @@ struct EncodeJob {
     uint64_t n;
     uint64_t cap;
     uint32_t kind;
-    uint32_t passes;     // digits of DIGIT_BITS bits in a key of the radix select (key < 2^(DIGIT_BITS * passes))
+    uint32_t passes;     // digits in a key of the radix select: ceil(key_bits / DIGIT_BITS)
     uint64_t min_b;      // min / max of (v ^ SIGN): unsigned order of the biased value = signed order
     uint64_t max_b;
     uint64_t next_above; // smallest key above the bracket (in key space once the bracket is verified), ~0 if none
@@ -64,7 +64,7 @@ struct EncodeJob {
     const void *sel_values;  // what the radix select reads: the array itself or its candidates
     uint64_t sel_n;
     uint32_t sel_kind;
-    uint32_t reserved;
+    uint32_t key_bits;   // bit length of the largest key of the radix select; digit i is bits [digit_shift(i), +DIGIT_BITS)
     // Candidate list (values inside the bracket): CAND_SEGS segments of seg_cap entries, segment s
     // filled from its start with counters->slot[s].cand_count entries.  Appends rotate over the
     // segments, so that they (and the below / inside counts, which live in the same slots) queue
@@ -225,6 +225,15 @@ __device__ __forceinline__ void for_each_array_run(const uint64_t *__restrict__ 
 
 __device__ __forceinline__ uint32_t bit_length64(uint64_t x) { return x ? 64u - (uint32_t)__builtin_clzll(x) : 0u; }
 
+// Digits of a select key of `bits` bits are taken from the top: digit i starts at this bit, so the
+// first digit always spans a full DIGIT_BITS bits of the keys' range (never a few leftover top
+// bits) and only the last one may be narrower: it then overlaps bits of the digit before it, which
+// are the same for all keys that share the earlier digits.
+__device__ __forceinline__ uint32_t digit_shift(uint32_t bits, uint32_t i) {
+    const uint32_t top = DIGIT_BITS * (i + 1);
+    return bits > top ? bits - top : 0u;
+}
+
 // bp64_pack's width rule (compression.rs:123-128) from max zig-zag value.
 __device__ __forceinline__ uint32_t width_of(uint64_t zmax) { return zmax ? bit_length64(zmax) : 1u; }
 
@@ -334,7 +343,8 @@ __global__ __launch_bounds__(SAMPLE_THREADS) void enc_sample_kernel(EncodeJob *_
     job.lo_b = r >= (uint64_t)margin ? sk[r - margin] : 0;
     job.hi_b = r + margin < (uint64_t)sample ? sk[r + margin] : ~0ull;
     job.key_base = job.lo_b;  // keys of a bracket select: (v ^ SIGN) - lo_b
-    job.passes = (bit_length64(job.hi_b - job.lo_b) + DIGIT_BITS - 1) / DIGIT_BITS;
+    job.key_bits = bit_length64(job.hi_b - job.lo_b);
+    job.passes = (job.key_bits + DIGIT_BITS - 1) / DIGIT_BITS;
     if (job.hi_b - job.lo_b < (uint64_t)BINS) { job.mode = SEL_BRACKET_HIST; job.passes = 1; }
     else if (job.seg_cap) job.mode = SEL_BRACKET_COMPACT;  // else stays SEL_FULL: no room for candidates
 }
@@ -423,7 +433,7 @@ __global__ __launch_bounds__(THREADS) void enc_bracket_kernel(EncodeJob *__restr
         constexpr uint32_t WAVES = THREADS / 64, WAVE_CAP = CAND_LDS / WAVES;
         static_assert(WAVE_CAP >= 2 * (TILE / CAND_PARTS / WAVES), "a wave appends at most TILE / CAND_PARTS / WAVES values between two looks");
         static_assert(PAIRS == 4, "a tile is handled in halves or quarters of its eight values per lane");
-        const uint32_t dsh = DIGIT_BITS * (job.passes - 1);  // wide bracket: the key's first digit
+        const uint32_t dsh = digit_shift(job.key_bits, 0);  // wide bracket: the key's first digit
         const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
         int64_t *wstage = lcand + wave * WAVE_CAP;
         uint32_t wcount = 0;  // uniform within the wave
@@ -607,14 +617,19 @@ __device__ __forceinline__ void finish_select(EncodeJob &job, uint64_t key_a, ui
 // s.k and descends into it.  By the whole workgroup; every lane gets the same state.
 // `next_key` = the smallest key above the picked bin as far as this histogram knows it: meaningful
 // only when this was the key's last digit (then a bin is one key), ~0 if no higher bin holds a key.
-__device__ __forceinline__ EncodeJob::SelState descend(EncodeJob::SelState s, const uint32_t *gh, BinPickShared *sh, uint64_t *next_key) {
+__device__ __forceinline__ EncodeJob::SelState descend(EncodeJob::SelState s, const uint32_t *gh, BinPickShared *sh, uint64_t *next_key,
+                                                       uint32_t bits) {
     uint32_t c[SEL_PER];
 #pragma unroll
     for (int i = 0; i < SEL_PER; i++) c[i] = gh[threadIdx.x * SEL_PER + i];
     const BinPick pk = pick_bin(c, s.k, sh);
-    const uint64_t high = s.lv == 0 ? 0 : s.prefix << DIGIT_BITS;
-    *next_key = pk.next_bin < (uint32_t)BINS ? (high | pk.next_bin) : ~0ull;
-    s.prefix = high | pk.bin;
+    // the digit's new bits: all DIGIT_BITS of them, except for a narrower last digit, whose bins
+    // repeat bits of the prefix in their upper part
+    const uint32_t d = s.lv == 0 ? (uint32_t)DIGIT_BITS : digit_shift(bits, s.lv - 1) - digit_shift(bits, s.lv);
+    const uint64_t low = (1ull << d) - 1;
+    const uint64_t high = s.lv == 0 ? 0 : s.prefix << d;
+    *next_key = pk.next_bin < (uint32_t)BINS ? (high | (pk.next_bin & low)) : ~0ull;
+    s.prefix = high | (pk.bin & low);
     s.k -= pk.before;
     s.cnt = pk.cnt;
     s.lv += 1;
@@ -697,7 +712,8 @@ __global__ __launch_bounds__(THREADS) void enc_setup_kernel(EncodeJob *__restric
                 j.mode = SEL_FULL;
                 j.key_base = j.min_b;
                 j.next_above = ~0ull;
-                j.passes = (bit_length64(span) + DIGIT_BITS - 1) / DIGIT_BITS;
+                j.key_bits = bit_length64(span);
+                j.passes = (j.key_bits + DIGIT_BITS - 1) / DIGIT_BITS;
                 j.flo = 0; j.fhi = ~0ull;
                 s0.k = k; s0.cnt = j.n; s0.action = ACT_NONE;
                 src_n = j.n;
@@ -715,7 +731,7 @@ __global__ __launch_bounds__(THREADS) void enc_setup_kernel(EncodeJob *__restric
         // the first digit is counted: pick its bin here, once, rather than in every workgroup of
         // the first level; a narrow bracket is finished by this
         uint64_t next_key = ~0ull;
-        s = descend(s, j.hist, &sh, &next_key);
+        s = descend(s, j.hist, &sh, &next_key, j.key_bits);
         if (threadIdx.x == 0 && s.lv == j.passes) {
             finish_digits(j, s, next_key);
             s.action = ACT_DONE;
@@ -738,11 +754,11 @@ __global__ __launch_bounds__(THREADS) void enc_setup_kernel(EncodeJob *__restric
 // ---- 4. radix select ---------------------------------------------------------------------
 
 // Keys that share s.prefix (s.lv digits resolved) in a key of `passes` digits.
-__device__ __forceinline__ bool shares_prefix(uint64_t key, const EncodeJob::SelState &s, uint32_t passes) {
-    return s.lv == 0 || (key >> (DIGIT_BITS * (passes - s.lv))) == s.prefix;
+__device__ __forceinline__ bool shares_prefix(uint64_t key, const EncodeJob::SelState &s, uint32_t bits) {
+    return s.lv == 0 || (key >> digit_shift(bits, s.lv - 1)) == s.prefix;
 }
-__device__ __forceinline__ bool above_prefix(uint64_t key, const EncodeJob::SelState &s, uint32_t passes) {
-    return s.lv != 0 && (key >> (DIGIT_BITS * (passes - s.lv))) > s.prefix;
+__device__ __forceinline__ bool above_prefix(uint64_t key, const EncodeJob::SelState &s, uint32_t bits) {
+    return s.lv != 0 && (key >> digit_shift(bits, s.lv - 1)) > s.prefix;
 }
 
 // ---- 4a. long select sources: up to SEL_LEVELS launches of many workgroups ----------------------
@@ -759,7 +775,7 @@ __device__ __forceinline__ bool above_prefix(uint64_t key, const EncodeJob::SelS
 
 // One workgroup's share (tiles w, w + eff, ...) of one array at level L.
 __device__ __forceinline__ void level_one(EncodeJob *__restrict__ jobs, uint32_t a, uint32_t w, uint32_t per_array, uint32_t tiles_per_wg,
-                                          uint32_t L, uint32_t *lh, BinPickShared *sh) {
+                                          uint32_t L, uint32_t *lh, BinPickShared *sh, uint32_t sparse_tiles) {
     EncodeJob &job = jobs[a];
     const uint32_t tid = threadIdx.x;
     const EncodeJob::SelState s0 = job.S[L - 1];
@@ -775,12 +791,12 @@ __device__ __forceinline__ void level_one(EncodeJob *__restrict__ jobs, uint32_t
     // A digit counted among keys that share earlier digits, and a gather, touch few counters:
     // nothing to merge, so every workgroup is worth having.
     const bool sparse = s0.action == ACT_HIST || s0.lv > 0;
-    if (sparse) tiles_per_wg = tiles_per_wg == 0 ? 8u : 2u;  // few arrays / many (measured: 1, 2, 4, 8, 16 tiles)
+    if (sparse) tiles_per_wg = sparse_tiles ? sparse_tiles : tiles_per_wg == 0 ? 8u : 2u;  // few arrays / many (measured: 1, 2, 4, 8, 16 tiles)
     else if (tiles_per_wg == 0) tiles_per_wg = work_tiles >= 4096 ? 16u : work_tiles < 512 ? 2u : (uint32_t)(work_tiles / 256);
     const uint64_t want = work_tiles / tiles_per_wg;
     const uint32_t eff = want < 1 ? 1u : want < per_array ? (uint32_t)want : per_array;
     if (w >= eff) return;
-    const uint32_t passes = job.passes;
+    const uint32_t passes = job.passes, bits = job.key_bits;
     EncodeJob::SelState s = s0;
     uint64_t next_key = ~0ull;
     if (s0.action == ACT_HIST && L >= 2 && s0.lv > 0 && job.match_min[L - 2] == job.match_max[L - 2]) {
@@ -792,7 +808,7 @@ __device__ __forceinline__ void level_one(EncodeJob *__restrict__ jobs, uint32_t
         }
         return;
     }
-    if (s0.action == ACT_HIST) s = descend(s0, L == 1 ? job.hist : job.lvl_hist + (size_t)(L - 2) * BINS, sh, &next_key);
+    if (s0.action == ACT_HIST) s = descend(s0, L == 1 ? job.hist : job.lvl_hist + (size_t)(L - 2) * BINS, sh, &next_key, bits);
     if (s.lv == passes) {
         if (w == 0 && tid == 0) {
             finish_digits(job, s, next_key);
@@ -814,7 +830,7 @@ __device__ __forceinline__ void level_one(EncodeJob *__restrict__ jobs, uint32_t
     if (gather) { if (tid == 0) stage_n = 0; }
     else for (uint32_t b = tid; b < BINS; b += THREADS) lh[b] = 0;
     __syncthreads();
-    const uint32_t shift = DIGIT_BITS * (passes - 1 - s.lv);  // of the digit to count
+    const uint32_t shift = digit_shift(bits, s.lv);  // of the digit to count
     const uint64_t base = job.key_base;
     // `above`: the smallest key above the keys that share the resolved digits.  It is what b falls
     // back on when this turns out to be the array's last read (a gather, the last digit, a run of
@@ -822,7 +838,7 @@ __device__ __forceinline__ void level_one(EncodeJob *__restrict__ jobs, uint32_t
     // per array serves them all.
     uint64_t above = ~0ull, kmin = ~0ull, kmax = 0;
     auto visit = [&](uint64_t key) {
-        if (shares_prefix(key, s, passes)) {
+        if (shares_prefix(key, s, bits)) {
             if (gather) {
                 const uint32_t slot = atomicAdd(&stage_n, 1u);
                 if (slot < GATHER_CAP) stage[slot] = key;  // always true while nobody writes the source: s.cnt keys in all
@@ -831,36 +847,69 @@ __device__ __forceinline__ void level_one(EncodeJob *__restrict__ jobs, uint32_t
                 kmin = min(kmin, key);
                 kmax = max(kmax, key);
             }
-        } else if (above_prefix(key, s, passes)) {
+        } else if (above_prefix(key, s, bits)) {
             above = min(above, key);
         }
     };
+    // A workgroup that looked at one tile at a time would pay a full memory latency per tile: the
+    // loads of up to LEVEL_AHEAD tiles are issued before the first is looked at.
+    constexpr int LEVEL_AHEAD = 4;
+    int64_t x[LEVEL_AHEAD][2 * PAIRS];
     if (!from_list) {
         const void *values = job.values;
         const uint32_t kind = job.kind;
         const uint64_t n = job.n, flo = job.flo, fhi = job.fhi;
-        for (uint64_t v0 = (uint64_t)w * TILE; v0 < n; v0 += (uint64_t)eff * TILE) {
-            int64_t x[2 * PAIRS];
-            load_tile_from(values, kind, v0, n, 0, x);
+        for (uint64_t v0 = (uint64_t)w * TILE; v0 < n; v0 += (uint64_t)LEVEL_AHEAD * eff * TILE) {
 #pragma unroll
-            for (int e = 0; e < 2 * PAIRS; ++e) {
-                const uint64_t i = v0 + tile_slot(kind, e);
-                const uint64_t b = (uint64_t)x[e] ^ SIGN;
-                if (i < n && b >= flo && b <= fhi) visit(b - base);
+            for (int u = 0; u < LEVEL_AHEAD; u++) {
+                const uint64_t t0 = v0 + (uint64_t)u * eff * TILE;
+                if (t0 < n) load_tile_from(values, kind, t0, n, 0, x[u]);
+            }
+#pragma unroll
+            for (int u = 0; u < LEVEL_AHEAD; u++) {
+                const uint64_t t0 = v0 + (uint64_t)u * eff * TILE;
+                if (t0 < n) {
+#pragma unroll
+                    for (int e = 0; e < 2 * PAIRS; ++e) {
+                        const uint64_t i = t0 + tile_slot(kind, e);
+                        const uint64_t b = (uint64_t)x[u][e] ^ SIGN;
+                        if (i < n && b >= flo && b <= fhi) visit(b - base);
+                    }
+                }
             }
         }
     } else {
-        const uint64_t seg_cap = job.seg_cap, seg_tiles = seg_cap / TILE;
-        for (uint64_t u = w; u < seg_tiles * CAND_SEGS; u += eff) {
-            const uint64_t sgm = u % CAND_SEGS, v0 = sgm * seg_cap + (u / CAND_SEGS) * TILE;
-            const uint64_t end = sgm * seg_cap + job.counters->slot[sgm].cand_count;  // values exist below this index
-            if (v0 >= end) continue;
-            int64_t x[2 * PAIRS];
-            load_tile_from(job.cand, ZBRA_ELEM_I64, v0, end, 0, x);
+        // the segmented list, seen as one space of tile slots (slot u = tile u / CAND_SEGS of segment
+        // u % CAND_SEGS), of which those below each segment's fill hold values
+        const uint64_t seg_cap = job.seg_cap, slots = seg_cap / TILE * CAND_SEGS;
+        uint64_t u = w;
+        while (u < slots) {  // uniform
+            uint64_t t0[LEVEL_AHEAD], end[LEVEL_AHEAD];
+            int m = 0;
 #pragma unroll
-            for (int e = 0; e < 2 * PAIRS; ++e) {
-                const uint64_t i = v0 + tile_slot(ZBRA_ELEM_I64, e);
-                if (i < end) visit(((uint64_t)x[e] ^ SIGN) - base);
+            for (int q = 0; q < LEVEL_AHEAD; q++) { t0[q] = 0; end[q] = 0; }
+            while (m < LEVEL_AHEAD && u < slots) {
+                const uint64_t sgm = u % CAND_SEGS, first = sgm * seg_cap + (u / CAND_SEGS) * TILE;
+                const uint64_t last = sgm * seg_cap + job.counters->slot[sgm].cand_count;  // values exist below this index
+                u += eff;
+                if (first >= last) continue;
+#pragma unroll
+                for (int q = 0; q < LEVEL_AHEAD; q++)
+                    if (q == m) { t0[q] = first; end[q] = last; }
+                m++;
+            }
+#pragma unroll
+            for (int q = 0; q < LEVEL_AHEAD; q++)
+                if (q < m) load_tile_from(job.cand, ZBRA_ELEM_I64, t0[q], end[q], 0, x[q]);
+#pragma unroll
+            for (int q = 0; q < LEVEL_AHEAD; q++) {
+                if (q < m) {
+#pragma unroll
+                    for (int e = 0; e < 2 * PAIRS; ++e) {
+                        const uint64_t i = t0[q] + tile_slot(ZBRA_ELEM_I64, e);
+                        if (i < end[q]) visit(((uint64_t)x[q][e] ^ SIGN) - base);
+                    }
+                }
             }
         }
     }
@@ -903,7 +952,8 @@ __device__ __forceinline__ void level_one(EncodeJob *__restrict__ jobs, uint32_t
 // `per_array` taking tiles w, w + per_array, ..., so that an array is never left to the two or
 // three workgroups that happen to own its stretch of the submission.  With nothing pending the
 // launch ends at its first load.
-__global__ __launch_bounds__(THREADS) void enc_level_kernel(EncodeJob *__restrict__ jobs, const uint32_t *__restrict__ pending, uint32_t L) {
+__global__ __launch_bounds__(THREADS) void enc_level_kernel(EncodeJob *__restrict__ jobs, const uint32_t *__restrict__ pending, uint32_t L,
+                                                             uint32_t sparse_tiles) {
     const uint32_t n_list = pending[0];
     if (n_list == 0) return;
     const uint32_t *list = pending + 1;
@@ -918,7 +968,7 @@ __global__ __launch_bounds__(THREADS) void enc_level_kernel(EncodeJob *__restric
     __shared__ uint32_t lh[BINS];
     __shared__ BinPickShared sh;
     for (uint64_t item = blockIdx.x; item < (uint64_t)n_list * per_array; item += gridDim.x)  // uniform
-        level_one(jobs, list[item / per_array], (uint32_t)(item % per_array), per_array, tiles_per_wg, L, lh, &sh);
+        level_one(jobs, list[item / per_array], (uint32_t)(item % per_array), per_array, tiles_per_wg, L, lh, &sh, sparse_tiles);
 }
 
 // ---- 4b. the finishing workgroup: one per array, every remaining digit in one launch -------------
@@ -995,7 +1045,7 @@ __global__ __launch_bounds__(THREADS) void enc_finish_select_kernel(EncodeJob *_
     if (blockIdx.x >= n_list) return;
     const uint32_t a = list[blockIdx.x];
     EncodeJob &job = jobs[a];
-    const uint32_t passes = job.passes, mode = job.mode;
+    const uint32_t passes = job.passes, bits = job.key_bits, mode = job.mode;
     if (passes == 0 || mode == SEL_DONE) return;
     __shared__ uint32_t lh[BINS];
     __shared__ uint64_t keep[KEEP];
@@ -1013,7 +1063,7 @@ __global__ __launch_bounds__(THREADS) void enc_finish_select_kernel(EncodeJob *_
         if (tid == 0) finish_run(job, s, job.match_min[at - 1]);  // the last level counted a digit of keys that are all the same
         return;
     }
-    if (s.action == ACT_HIST) s = descend(s, at == 0 ? job.hist : job.lvl_hist + (size_t)(at - 1) * BINS, &sh, &next_key);
+    if (s.action == ACT_HIST) s = descend(s, at == 0 ? job.hist : job.lvl_hist + (size_t)(at - 1) * BINS, &sh, &next_key, bits);
     // the smallest key above the keys that share the resolved digits, as far as earlier launches know
     auto above_so_far = [&]() -> uint64_t {
         const uint64_t x = (uint64_t)job.above_key < job.next_above ? (uint64_t)job.above_key : job.next_above;
@@ -1057,10 +1107,10 @@ __global__ __launch_bounds__(THREADS) void enc_finish_select_kernel(EncodeJob *_
             __syncthreads();
             uint64_t above = ~0ull;
             for_each_select_key(job, mode, [&](uint64_t key) {
-                if (shares_prefix(key, s, passes)) {
+                if (shares_prefix(key, s, bits)) {
                     const uint32_t slot = atomicAdd(&keep_n, 1u);
                     if (slot < KEEP) keep[slot] = key;  // always true while nobody writes the source
-                } else if (above_prefix(key, s, passes)) {
+                } else if (above_prefix(key, s, bits)) {
                     above = min(above, key);
                 }
             });
@@ -1070,15 +1120,15 @@ __global__ __launch_bounds__(THREADS) void enc_finish_select_kernel(EncodeJob *_
             return;
         }
         // count the next digit of the keys that share the resolved ones
-        const uint32_t shift = DIGIT_BITS * (passes - 1 - s.lv);
+        const uint32_t shift = digit_shift(bits, s.lv);
         const bool last_digit = s.lv + 1 == passes;
         __syncthreads();
         for (uint32_t b = tid; b < (uint32_t)BINS; b += THREADS) lh[b] = 0;
         __syncthreads();
         uint64_t above = ~0ull;
         for_each_select_key(job, mode, [&](uint64_t key) {
-            if (shares_prefix(key, s, passes)) atomicAdd(&lh[(uint32_t)(key >> shift) & (BINS - 1)], 1u);
-            else if (last_digit && above_prefix(key, s, passes)) above = min(above, key);
+            if (shares_prefix(key, s, bits)) atomicAdd(&lh[(uint32_t)(key >> shift) & (BINS - 1)], 1u);
+            else if (last_digit && above_prefix(key, s, bits)) above = min(above, key);
         });
         if (last_digit) {
             above = wave_min_u64(above);
@@ -1086,7 +1136,7 @@ __global__ __launch_bounds__(THREADS) void enc_finish_select_kernel(EncodeJob *_
         }
         __syncthreads();
         s.action = ACT_HIST;
-        s = descend(s, lh, &sh, &next_key);
+        s = descend(s, lh, &sh, &next_key, bits);
     }
 }
 
@@ -1359,6 +1409,60 @@ __device__ __forceinline__ void pack_tile_raw(const EncodeJob &job, uint64_t v0,
     }
 }
 
+// The same for int64 (or plain u64) values at an 8-byte aligned address, which is every caller but
+// the odd one: each lane builds whole 16-byte chunks of the OUTPUT memory image from the two
+// 16-byte aligned chunks of the INPUT that hold their bytes (four whole values: zig-zag each,
+// then a byte funnel by the distance between the two alignments, which is one number per tile).
+// Two aligned 16-byte loads per aligned 16-byte store, against three 8-byte loads above.  A chunk
+// of the input is only loaded when it holds at least one byte of the array, so it lies in a mapped
+// page; bytes of values outside the tile land in output bytes outside the tile, which are not stored.
+__device__ __forceinline__ void pack_tile_raw_aligned(const EncodeJob &job, uint64_t v0, uint32_t nv) {
+    const uint32_t tid = threadIdx.x;
+    const uint64_t mid = (uint64_t)job.midpoint;
+    const bool plain = job.kind == KIND_U64_PLAIN;
+    const uintptr_t G = (uintptr_t)job.out + 13 + v0 * 8;
+    const uint32_t nbytes = nv * 8u;
+    const uintptr_t Gend = G + nbytes;
+    const uintptr_t G0 = G & ~(uintptr_t)15;
+    const uint32_t off = (uint32_t)(G - G0);
+    const uint32_t nchunks = (off + nbytes + 15u) >> 4;
+    const uintptr_t in_begin = (uintptr_t)job.values, in_end = in_begin + job.n * 8;
+    const uintptr_t in0 = in_begin + v0 * 8 - off;          // input byte that lands on output byte G0
+    const uint32_t r = (uint32_t)(in0 & 15u), q = r >> 2, rb = r & 3u;
+    const uintptr_t A = in0 - r;                             // 16-byte aligned
+    for (uint32_t c = tid; c < nchunks; c += THREADS) {
+        const uintptr_t a0 = A + (uintptr_t)c * 16;
+        u64x2 x = {0, 0}, y = {0, 0};
+        if (a0 + 16 > in_begin && a0 < in_end) x = __builtin_nontemporal_load(gptr<u64x2>(a0));
+        if (r != 0 && a0 + 32 > in_begin && a0 + 16 < in_end) y = __builtin_nontemporal_load(gptr<u64x2>(a0 + 16));
+        uint64_t z[4] = {x.x, x.y, y.x, y.y};
+        if (!plain) {
+#pragma unroll
+            for (int e = 0; e < 4; e++) z[e] = zigzag_encode64((int64_t)(z[e] - mid));
+        }
+        const uint32_t a[8] = {(uint32_t)z[0], (uint32_t)(z[0] >> 32), (uint32_t)z[1], (uint32_t)(z[1] >> 32),
+                               (uint32_t)z[2], (uint32_t)(z[2] >> 32), (uint32_t)z[3], (uint32_t)(z[3] >> 32)};
+        uint32_t o[4];
+        switch (q) {
+            case 0: funnel_bytes<0>(a, rb, o); break;
+            case 1: funnel_bytes<1>(a, rb, o); break;
+            case 2: funnel_bytes<2>(a, rb, o); break;
+            default: funnel_bytes<3>(a, rb, o); break;
+        }
+        const uintptr_t addr = G0 + (uintptr_t)c * 16;
+        if (addr >= G && addr + 16 <= Gend) {
+            u32x4 v = {o[0], o[1], o[2], o[3]};
+            __builtin_nontemporal_store(v, gptr_mut<u32x4>(addr));
+        } else {  // head / tail chunk shared with a neighbour: only this tile's bytes
+#pragma unroll
+            for (int b = 0; b < 16; b++) {
+                const uintptr_t p = addr + b;
+                if (p >= G && p < Gend) *gptr_mut<uint8_t>(p) = (uint8_t)(o[b >> 2] >> (8 * (b & 3)));
+            }
+        }
+    }
+}
+
 // frame_of_reference_encode alone: copies each array's midpoint to its result words.
 __global__ void enc_report_median_kernel(const EncodeJob *__restrict__ jobs, uint32_t nd, zbra_dev_result *results) {
     const uint32_t a = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1384,6 +1488,7 @@ __global__ __launch_bounds__(THREADS) void enc_pack_kernel(const EncodeJob *__re
         const uint32_t nv = left < (uint64_t)TILE ? (uint32_t)left : (uint32_t)TILE;
         if (job.width - (NARROW_W + 1) < 31u - NARROW_W) pack_tile_packed(job, v0, nv, zz);  // NARROW_W < w < 32
         else if (job.width <= NARROW_W) pack_tile_narrow(job, v0, nv, zz);
+        else if (job.kind != ZBRA_ELEM_U32 && ((uintptr_t)job.values & 7u) == 0) pack_tile_raw_aligned(job, v0, nv);
         else pack_tile_raw(job, v0, nv);
     }
 }
