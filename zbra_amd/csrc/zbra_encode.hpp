@@ -296,9 +296,94 @@ __device__ __forceinline__ void sort_keys_lds(uint64_t *sk, uint32_t m) {
     __syncthreads();
 }
 
+// Two order statistics of up to SAMPLE keys, by one workgroup of SAMPLE_THREADS lanes that keep
+// their keys in registers: radix select on (key - smallest key), DIGIT_BITS bits a pass from the
+// top, both ranks at once (two histograms in LDS, one scan).  ceil(bits(largest - smallest) / 12)
+// passes of about 2 us, against 31 us for sorting 4096 keys in LDS, of which only two were looked at.
+constexpr int SAMPLE_PER = SAMPLE / SAMPLE_THREADS;  // keys per lane
+struct SampleShared {
+    uint32_t hist[2][BINS];
+    uint64_t wave_lo[SAMPLE_THREADS / 64], wave_hi[SAMPLE_THREADS / 64];
+    uint32_t wave_sum[2][SAMPLE_THREADS / 64];
+    uint32_t bin[2], before[2];
+};
+// key[i] valid for i < nvalid (this lane's keys); ranks r0 <= r1 < total valid keys.  Returns the
+// keys of rank r0 and r1 in out[0], out[1], the smallest and largest key in out[2], out[3].  Every
+// lane gets the same answer.
+__device__ __forceinline__ void select_two_ranks(const uint64_t (&key)[SAMPLE_PER], uint32_t nvalid, uint32_t r0, uint32_t r1,
+                                                 SampleShared *sh, uint64_t (&out)[4]) {
+    const uint32_t tid = threadIdx.x, wave = tid >> 6, lane = tid & 63u;
+    constexpr uint32_t WAVES = SAMPLE_THREADS / 64;
+    uint64_t lo = ~0ull, hi = 0;
+#pragma unroll
+    for (int i = 0; i < SAMPLE_PER; i++)
+        if ((uint32_t)i < nvalid) { lo = min(lo, key[i]); hi = max(hi, key[i]); }
+    lo = wave_min_u64(lo); hi = wave_max_u64(hi);
+    if (lane == 0) { sh->wave_lo[wave] = lo; sh->wave_hi[wave] = hi; }
+    __syncthreads();
+    for (uint32_t w = 0; w < WAVES; w++) { lo = min(lo, sh->wave_lo[w]); hi = max(hi, sh->wave_hi[w]); }
+    out[2] = lo; out[3] = hi;
+    const uint32_t bits = bit_length64(hi - lo), passes = (bits + DIGIT_BITS - 1) / DIGIT_BITS;
+    uint64_t prefix[2] = {0, 0};
+    uint32_t k[2] = {r0, r1};
+    for (uint32_t lv = 0; lv < passes; lv++) {  // uniform
+        for (uint32_t b = tid; b < 2u * BINS; b += SAMPLE_THREADS) (&sh->hist[0][0])[b] = 0;
+        __syncthreads();
+        const uint32_t shift = digit_shift(bits, lv), up = lv ? digit_shift(bits, lv - 1) : 0u;
+#pragma unroll
+        for (int i = 0; i < SAMPLE_PER; i++) {
+            if ((uint32_t)i < nvalid) {
+                const uint64_t rel = key[i] - lo;
+                const uint32_t digit = (uint32_t)(rel >> shift) & (BINS - 1);
+                if (lv == 0 || (rel >> up) == prefix[0]) atomicAdd(&sh->hist[0][digit], 1u);
+                if (lv == 0 || (rel >> up) == prefix[1]) atomicAdd(&sh->hist[1][digit], 1u);
+            }
+        }
+        __syncthreads();
+        // lane t brings bins [4t, 4t + 4) of both histograms; exclusive scan over the workgroup
+        uint32_t c[2][BINS / SAMPLE_THREADS], sum[2], incl[2];
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            sum[h] = 0;
+#pragma unroll
+            for (int q = 0; q < BINS / SAMPLE_THREADS; q++) { c[h][q] = sh->hist[h][tid * (BINS / SAMPLE_THREADS) + q]; sum[h] += c[h][q]; }
+            incl[h] = sum[h];
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) { const uint32_t t = __shfl_up(incl[h], o); if (lane >= (uint32_t)o) incl[h] += t; }
+            if (lane == 63) sh->wave_sum[h][wave] = incl[h];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            uint32_t before = incl[h] - sum[h];
+            for (uint32_t w = 0; w < wave; w++) before += sh->wave_sum[h][w];
+            if (k[h] >= before && k[h] < before + sum[h]) {  // exactly one lane
+                uint32_t run = before;
+#pragma unroll
+                for (int q = 0; q < BINS / SAMPLE_THREADS; q++) {
+                    if (k[h] >= run && k[h] < run + c[h][q]) { sh->bin[h] = tid * (BINS / SAMPLE_THREADS) + q; sh->before[h] = run; }
+                    run += c[h][q];
+                }
+            }
+        }
+        __syncthreads();
+        const uint32_t d = lv == 0 ? (uint32_t)DIGIT_BITS : up - shift;
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            prefix[h] = (lv == 0 ? 0 : prefix[h] << d) | (sh->bin[h] & ((1u << d) - 1u));
+            k[h] -= sh->before[h];
+        }
+        // the next pass's zeroing of the histograms comes after every lane has read bin / before:
+        // the barrier at the top of its counting loop is behind the zeroing, so add one here
+        __syncthreads();
+    }
+    out[0] = lo + prefix[0];
+    out[1] = lo + prefix[1];
+}
+
 // One workgroup per array.
 __global__ __launch_bounds__(SAMPLE_THREADS) void enc_sample_kernel(EncodeJob *__restrict__ jobs, uint32_t nd, uint32_t use_bracket) {
-    __shared__ uint64_t sk[SAMPLE];
+    __shared__ SampleShared sh;
     const uint32_t a = blockIdx.x;
     if (a >= nd) return;
     EncodeJob &job = jobs[a];
@@ -307,41 +392,48 @@ __global__ __launch_bounds__(SAMPLE_THREADS) void enc_sample_kernel(EncodeJob *_
 
     const bool whole = n <= (uint64_t)SAMPLE;
     // An array too short for a candidate list (seg_cap == 0) only asks the sample whether its
-    // bracket is narrow enough for the histogram route: a quarter of the keys answers that, and
-    // sorting them takes a quarter of the time (the sort is most of this kernel: 44 us at 4096 keys).
-    const uint32_t sample = job.seg_cap ? (uint32_t)SAMPLE : (uint32_t)SAMPLE / 4;
+    // bracket is narrow enough for the histogram route: a quarter of the keys answers that.
+    const uint32_t sample = whole ? (uint32_t)n : job.seg_cap ? (uint32_t)SAMPLE : (uint32_t)SAMPLE / 4;
     const uint32_t margin = job.seg_cap ? (uint32_t)SAMPLE_MARGIN : (uint32_t)SAMPLE_MARGIN / 2;  // 4 sigma of sqrt(sample) / 2
     const uint64_t stride = whole ? 1 : n / sample;
-    uint32_t m = sample;  // keys to sort: the next power of two >= n for a short array
-    if (whole) { m = 2; while (m < (uint32_t)n) m <<= 1; }
-    for (uint32_t j = threadIdx.x; j < m; j += SAMPLE_THREADS) {
-        uint64_t key = ~0ull;  // padding of a short array sorts to the end
-        if (whole) {
-            if (j < n) key = (uint64_t)load_value(job, j) ^ SIGN;
-        } else {
-            // one value from each of `sample` equal strides, at a hashed offset inside it, so that
-            // periodic data does not alias with the sampling step
-            uint64_t h = (j + 1) * 0x9E3779B97F4A7C15ull;
-            h ^= h >> 29; h *= 0xBF58476D1CE4E5B9ull; h ^= h >> 32;
-            key = (uint64_t)load_value(job, (uint64_t)j * stride + h % stride) ^ SIGN;
+    uint64_t key[SAMPLE_PER];
+    uint32_t nvalid = 0;  // this lane holds keys j = tid + i * SAMPLE_THREADS, i < nvalid
+#pragma unroll
+    for (int i = 0; i < SAMPLE_PER; i++) {
+        const uint32_t j = threadIdx.x + (uint32_t)i * SAMPLE_THREADS;
+        key[i] = 0;
+        if (j < sample) {
+            uint64_t at = j;
+            if (!whole) {
+                // one value from each of `sample` equal strides, at a hashed offset inside it, so that
+                // periodic data does not alias with the sampling step
+                uint64_t h = (j + 1) * 0x9E3779B97F4A7C15ull;
+                h ^= h >> 29; h *= 0xBF58476D1CE4E5B9ull; h ^= h >> 32;
+                at = (uint64_t)j * stride + h % stride;
+            }
+            key[i] = (uint64_t)load_value(job, at) ^ SIGN;
+            nvalid = (uint32_t)i + 1;
         }
-        sk[j] = key;
     }
-    sort_keys_lds<SAMPLE_THREADS>(sk, m);
-    if (threadIdx.x != 0) return;
     const uint64_t k = (n - 1) / 2;  // rank of a: n/2 - 1 for even n, n/2 for odd n
-    if (whole) {
-        job.min_b = sk[0]; job.max_b = sk[n - 1];
+    uint64_t got[4];
+    if (whole) {  // every value is in the sample: a, b, min and max fall out directly
+        const bool even = (n & 1) == 0;
+        select_two_ranks(key, nvalid, (uint32_t)k, (uint32_t)(even ? k + 1 : k), &sh, got);
+        if (threadIdx.x != 0) return;
+        job.min_b = got[2]; job.max_b = got[3];
         job.need_or = job.max_b - job.min_b >= SIGN;
         job.passes = 0;
         job.mode = SEL_DONE;
-        const bool even = (n & 1) == 0;
-        set_midpoint(job, (int64_t)(sk[k] ^ SIGN), (int64_t)(sk[even ? k + 1 : k] ^ SIGN), even);
+        set_midpoint(job, (int64_t)(got[0] ^ SIGN), (int64_t)(got[1] ^ SIGN), even);
         return;
     }
     const uint64_t r = (uint64_t)(((unsigned __int128)k * sample) / n);  // expected sample rank of a
-    job.lo_b = r >= (uint64_t)margin ? sk[r - margin] : 0;
-    job.hi_b = r + margin < (uint64_t)sample ? sk[r + margin] : ~0ull;
+    const bool has_lo = r >= (uint64_t)margin, has_hi = r + margin < (uint64_t)sample;
+    select_two_ranks(key, nvalid, has_lo ? (uint32_t)(r - margin) : 0u, has_hi ? (uint32_t)(r + margin) : sample - 1, &sh, got);
+    if (threadIdx.x != 0) return;
+    job.lo_b = has_lo ? got[0] : 0;
+    job.hi_b = has_hi ? got[1] : ~0ull;
     job.key_base = job.lo_b;  // keys of a bracket select: (v ^ SIGN) - lo_b
     job.key_bits = bit_length64(job.hi_b - job.lo_b);
     job.passes = (job.key_bits + DIGIT_BITS - 1) / DIGIT_BITS;
