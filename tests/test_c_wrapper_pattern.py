@@ -1,0 +1,32 @@
+"""Runs tests/c/test_wrapper_pattern.c: the C ABI driven from plain C in the allocate / call /
+truncate pattern of the Rust wrappers (rust/zbra-hip-sys), every result against the CPU oracle."""
+import os
+import subprocess
+
+import pytest
+
+from conftest import ROOT
+
+EXE = os.path.join(ROOT, "tests", "c", "test_wrapper_pattern")
+
+
+def _ensure_built():
+    if not os.path.exists(EXE):
+        subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "tests", "c")])
+
+
+@pytest.mark.gpu
+def test_wrapper_pattern_on_gpu():
+    _ensure_built()
+    p = subprocess.run([EXE], capture_output=True, text=True, timeout=120)
+    assert p.returncode == 0, p.stdout + p.stderr
+    assert " 0 failures" in p.stdout
+
+
+def test_wrapper_pattern_refuses_without_device():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    _ensure_built()
+    p = subprocess.run([EXE], capture_output=True, text=True, timeout=60)
+    assert p.returncode == 2 and "need a GPU" in p.stdout
