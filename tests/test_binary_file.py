@@ -147,7 +147,53 @@ def test_index_rejects_bad_images():
             pass
 
 
+def _golden_file():
+    import json
+    import os
+    from conftest import ROOT
+    with open(os.path.join(ROOT, "tests", "golden", "known_answers.json")) as f:
+        return json.load(f)["file"][0]
+
+
+def _golden_file_tree(zb, vec):
+    values = np.array([int(v) for v in vec["values"]], dtype=np.int64)
+    return zb.BinaryFile(vec["schema_json"], [zb.Block(len(values), zb.ArrayTable(zb.Int(values)))], vec["compression_json"])
+
+
+def test_hand_built_image_of_the_reference_round_trip_test_cpu():
+    """The image of binary.rs:708-741 (BinaryFile::new of an Int column 1..5, default compression
+    config), typed by hand in scripts/make_golden.py: the writer's tree walk with the oracle as
+    codec produces exactly these 228 bytes, and the walker finds the one array in it."""
+    from zbra_amd import binary as zb
+    vec = _golden_file()
+    want = bytes.fromhex(vec["hand"]["hex"])
+    assert len(want) == vec["hand"]["len"] == 228
+    assert _golden_file_tree(zb, vec).to_bytes(OracleCodec) == want
+    info, arrays = zb.file_index(want)
+    assert info.block_count == 1 and info.n_arrays == 1 and info.end_offset == len(want)
+    assert (arrays[0].count, arrays[0].len, arrays[0].role, arrays[0].kind) == (5, 15, 0, 0)
+    assert want[arrays[0].offset:arrays[0].offset + 15].hex() == "030000000000000003000000030b44"
+    assert want[info.schema_offset:info.schema_offset + info.schema_len].decode() == vec["schema_json"]
+    # a table with byte blobs cannot be written under a zstd config here: zstd is another path
+    blob = zb.BinaryFile("{}", [zb.Block(1, zb.ArrayTable(zb.Binary(np.array([2], dtype=np.uint64), b"hi")))], vec["compression_json"])
+    with pytest.raises(NotImplementedError):
+        blob.to_bytes(OracleCodec)
+
+
 # ---- GPU: writer + two-phase reader -------------------------------------------------------------
+
+@pytest.mark.gpu
+def test_hand_built_image_of_the_reference_round_trip_test_gpu():
+    from zbra_amd import binary as zb
+    vec = _golden_file()
+    want = bytes.fromhex(vec["hand"]["hex"])
+    f = _golden_file_tree(zb, vec)
+    assert f.to_bytes() == want
+    back = zb.BinaryFile.from_bytes(want)
+    assert back.schema_json == vec["schema_json"] and back.compression_json == vec["compression_json"]
+    assert len(back.blocks) == 1 and back.blocks[0].row_count == 5
+    assert _trees_equal(zb, back.blocks[0].table, f.blocks[0].table)
+
 
 @pytest.mark.gpu
 def test_small_time_series_roundtrip():

@@ -13,6 +13,7 @@ ORACLES = [("c", oc), ("numpy", on)]
 
 @pytest.mark.parametrize("name,o", ORACLES)
 def test_golden_pipeline(golden, name, o):
+    assert [v["name"] for v in golden["pipeline"] if not v["hand"]["hex"]] == ["M"]  # 643 bytes: too long to type
     for vec in golden["pipeline"]:
         values = [int(v) for v in vec["values"]]
         e = o.compress_int_array(values)
@@ -48,7 +49,7 @@ def test_golden_stages_published_by_the_reference(golden, name, o):
         zz = o.zig_zag_encode(deltas)
         assert [int(z) for z in zz] == [int(z) for z in pub["zigzag"]]
         assert o.bp64_pack(zz)[0] == pub["w"]
-        assert o.compress_int_array(values).hex() == vec["hex"]
+        assert o.compress_int_array(values).hex() == vec["hex"] == vec["hand"]["hex"]  # bytes derived by hand from the published numbers
 
 
 @pytest.mark.parametrize("kind", KINDS)

@@ -133,9 +133,11 @@ class _Writer:
     at the end (`finish`), their frames then spliced in where the walk met them; with a
     per-array codec (a test's stand-in) each array is encoded on the spot, as the reference does."""
 
-    def __init__(self, codec):
+    def __init__(self, codec, blobs_stored=(True, True)):
         self.out = bytearray()
         self.codec = codec
+        # CompressionAlgorithm::None for (binary_data, strings): only then can a byte blob be written here
+        self.blobs_stored = blobs_stored
         self.batched = hasattr(codec, "write_int_arrays_compressed")
         self.pending = []                                  # (position in self.out, array)
 
@@ -167,6 +169,11 @@ class _Writer:
         self.u32(len(b))
         self.u32(len(b))
         self.out += b
+
+    def zblob(self, data, which):                          # write_sized_byte_array_compressed :677-687
+        if not self.blobs_stored[which]:
+            raise NotImplementedError("byte blobs are written with CompressionAlgorithm::None only (zstd is another path)")
+        self.sized(bytes(data))                            # compress_binary(None) = the bytes as they are
 
     def encoding(self, kind, name):                        # :507-519
         if kind == "int":
@@ -208,7 +215,7 @@ class _Writer:
         elif isinstance(c, Binary):
             self.u8(3); self.u8(c.default); self.encoding("binary", c.encoding)
             self.int_array(np.asarray(c.lengths, dtype=np.uint64).view(np.int64))
-            self.sized(bytes(c.data))                      # CompressionAlgorithm::None: stored as is
+            self.zblob(c.data, 1)                          # compression.strings
         elif isinstance(c, Array):
             self.u8(4); self.u8(c.default)
             self.int_array(np.asarray(c.lengths, dtype=np.uint64).view(np.int64))
@@ -230,7 +237,7 @@ class _Writer:
 
     def table(self, t):                                    # Table::write_to :204-237
         if isinstance(t, BinaryTable):
-            self.u8(0); self.u8(t.default); self.encoding("binary", t.encoding); self.sized(bytes(t.data))
+            self.u8(0); self.u8(t.default); self.encoding("binary", t.encoding); self.zblob(t.data, 0)  # compression.binary_data
         elif isinstance(t, ArrayTable):
             self.u8(1); self.u8(t.default); self.column(t.column)
         elif isinstance(t, MapTable):
@@ -378,9 +385,8 @@ class BinaryFile:                            # binary.rs:56-59
 
     def to_bytes(self, codec=_gpu) -> bytes:               # write_to :103-130
         cfg = json.loads(self.compression_json)
-        if cfg.get("binary_data") != "None" or cfg.get("strings") != "None":
-            raise NotImplementedError("byte blobs are written with CompressionAlgorithm::None only")
-        w = _Writer(codec)
+        # a table without byte blobs (int, double, enum, array columns) is written under any config
+        w = _Writer(codec, (cfg.get("binary_data") == "None", cfg.get("strings") == "None"))
         w.out += MAGIC_NUMBER
         w.sized(self.schema_json.encode())
         w.sized(self.compression_json.encode())
