@@ -102,6 +102,7 @@ struct IntArrayRef {
     const void *values;
     size_t n;
     bool is_u32;
+    IntArrayRef(const void *p, size_t count, bool narrow) : values(p), n(count), is_u32(narrow) {}
     IntArrayRef(const std::vector<int64_t> &v) : values(v.data()), n(v.size()), is_u32(false) {}
     IntArrayRef(const std::vector<uint32_t> &v) : values(v.data()), n(v.size()), is_u32(true) {}
 };
@@ -152,13 +153,17 @@ inline Result<DecodedFile> read_file_int_arrays(const uint8_t *image, size_t len
     std::vector<void *> outs(idx.size());
     for (size_t i = 0; i < idx.size(); i++) {
         f.arrays[i].where = idx[i];
-        if (idx[i].kind == ZBRA_ELEM_U32) { f.arrays[i].u32.resize(idx[i].count); outs[i] = f.arrays[i].u32.data(); }
-        else { f.arrays[i].i64.resize(idx[i].count); outs[i] = f.arrays[i].i64.data(); }
+        // the length of the Vec decompress_int_array returns: 0 for empty data and for an empty
+        // packed slice whatever the frame's count says (compression.rs:296-298, 182-184)
+        size_t n = 0;
+        st = zbra_hip_decoded_count(image + idx[i].offset, idx[i].len, idx[i].count, &n);
+        if (st != ZBRA_OK) return detail::make_error(st, BinaryError::DecompressionError);
+        if (idx[i].kind == ZBRA_ELEM_U32) { f.arrays[i].u32.resize(n); outs[i] = f.arrays[i].u32.data(); }
+        else { f.arrays[i].i64.resize(n); outs[i] = f.arrays[i].i64.data(); }
+        idx[i].count = n;  // what is asked of the decode: an array that yields nothing has no output buffer
     }
     st = zbra_hip_file_decode(image, len, idx.data(), idx.size(), outs.data(), nullptr);
     if (st != ZBRA_OK) return detail::make_error(st, BinaryError::DecompressionError);
-    for (size_t i = 0; i < idx.size(); i++)
-        if (idx[i].len == 0) { f.arrays[i].i64.clear(); f.arrays[i].u32.clear(); }  // empty data -> empty Vec, compression.rs:296-298
     return f;
 }
 

@@ -145,3 +145,21 @@ def gen_narrow(seed: int, first: int, n: int) -> np.ndarray:
     out = np.empty(n, dtype=np.int64)
     lib.zo_gen_narrow(seed, first, n, _ptr(out))
     return out
+
+
+def compress_int_array_stable_sort_into(values: np.ndarray, out: np.ndarray) -> int:
+    """The timed CPU encode baseline: the same stages with the median's sort done by an
+    inlined-compare stable merge sort, as Rust's Vec::sort is (oracle/zbra_baseline_sort.cpp).
+    Same bytes as compress_int_array_into.  Loads libzbra_baseline.so on first use."""
+    global _baseline
+    if _baseline is None:
+        so = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libzbra_baseline.so")
+        if not os.path.exists(so):
+            raise ImportError(f"{so} is missing: run `make -C oracle`")
+        _baseline = C.CDLL(so)
+        _baseline.zb_compress_int_array_stable_sort.restype = C.c_size_t
+        _baseline.zb_compress_int_array_stable_sort.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p]
+    return _baseline.zb_compress_int_array_stable_sort(_ptr(values), values.size, _ptr(out))
+
+
+_baseline = None

@@ -147,3 +147,15 @@ def test_headline_column_width_is_12():
     v = oc.gen_narrow(0x5EED0002, 0, 1 << 16)
     e = oc.compress_int_array(v)
     assert e[12] == 12 and len(e) == 13 + (v.size * 12 + 7) // 8
+
+
+@pytest.mark.parametrize("kind", KINDS)
+def test_timed_baseline_with_stable_sort_gives_the_oracles_bytes(kind):
+    """bench.py times the CPU encode with an inlined-compare stable sort (oracle/zbra_baseline_sort.cpp):
+    same bytes as the statement-by-statement port, whatever the sort."""
+    for n in (1, 2, 7, 4096, 10001):
+        v = column(kind, n, seed=n + 3)
+        want = oc.compress_int_array(v)
+        buf = np.empty(13 + 8 * n, dtype=np.uint8)
+        got = oc.compress_int_array_stable_sort_into(np.ascontiguousarray(v), buf)
+        assert buf[:got].tobytes() == want, (kind, n)
