@@ -17,6 +17,7 @@ def main():
     ap.add_argument("--reps", type=int, default=10)
     ap.add_argument("--rows-log2", type=int, default=28)
     ap.add_argument("--tags", action="store_true", help="u32 tag column instead of the int64 column")
+    ap.add_argument("--amp-bits", type=int, default=0, help="int64 column of this amplitude (the width sweep's generator) instead")
     args = ap.parse_args()
     import torch
 
@@ -26,6 +27,10 @@ def main():
     if args.tags:
         tags, _ = workloads.enum_block(0, n, dev)
         values = tags
+    elif args.amp_bits:
+        rnd = workloads.sm(0xABCDEF, torch.arange(n, dtype=torch.int64, device=dev))
+        values = rnd if args.amp_bits == 64 else (rnd & ((1 << args.amp_bits) - 1)) - (1 << (args.amp_bits - 1)) + 1_000_000_007
+        del rnd
     else:
         values = workloads.narrow_column(0x5EED0002, 0, n, dev)
     enc = torch.empty(device.encode_bound(n), dtype=torch.uint8, device=dev)

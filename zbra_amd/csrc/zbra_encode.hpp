@@ -447,6 +447,7 @@ __global__ __launch_bounds__(SAMPLE_THREADS) void enc_sample_kernel(EncodeJob *_
 struct BracketAcc {
     uint64_t lo = ~0ull, hi = 0, above = ~0ull;
     uint32_t below = 0, inb = 0;
+    uint32_t first = 0;  // two-key bracket: values equal to its lower key
 };
 // Brackets of at most MICRO_KEYS keys (enum tags, booleans): a shared LDS histogram would take
 // every lane's atomic on the same few addresses, which serialise.  Each lane counts in its own
@@ -455,6 +456,11 @@ struct BracketAcc {
 constexpr uint32_t MICRO_KEYS = 8;
 static_assert(MICRO_KEYS * THREADS <= (uint32_t)BINS, "the private columns live in the histogram pool");
 constexpr uint32_t SEL_BRACKET_MICRO = 100;  // template tag only: a histogram-mode array with a tiny bracket
+// A bracket of ONE key (more than 6 % of the values are the median: a popular tag, a boolean, a
+// default value) needs no histogram at all, its one bin is the count of values inside; a bracket
+// of TWO keys needs one more count.  These are the usual tiny brackets, and without the per-value
+// LDS access the pass runs at the rate of the plain histogram route.
+constexpr uint32_t SEL_BRACKET_ONE = 101, SEL_BRACKET_TWO = 102;  // template tags only
 
 // Values x[E0..E1) of a tile.  MODE and WHOLE (the tile lies wholly inside the array) are
 // compile-time so that the loop body is straight-line code with one branch (the append).
@@ -474,7 +480,11 @@ __device__ __forceinline__ void bracket_values(const int64_t (&x)[2 * PAIRS], ui
             acc.below += is_below;
             acc.inb += inside;
             acc.above = is_above && b < acc.above ? b : acc.above;
-            if (MODE == SEL_BRACKET_MICRO) {
+            if (MODE == SEL_BRACKET_ONE) {
+                // nothing: the bin is acc.inb
+            } else if (MODE == SEL_BRACKET_TWO) {
+                acc.first += inside && b == lo_b;
+            } else if (MODE == SEL_BRACKET_MICRO) {
                 if (inside) lh[((uint32_t)(b - lo_b) & (MICRO_KEYS - 1)) * THREADS + threadIdx.x] += 1u;
             } else if (MODE == SEL_BRACKET_COMPACT) {
                 // wave-private staging: the ballot gives every lane its slot, no atomic, no barrier
@@ -499,15 +509,18 @@ __global__ __launch_bounds__(THREADS) void enc_bracket_kernel(EncodeJob *__restr
     __shared__ uint32_t lh[BINS];
     __shared__ __attribute__((aligned(16))) int64_t lcand[CAND_LDS];
     __shared__ unsigned long long lbelow, linb; // this run's counts
+    __shared__ uint32_t lfirst;                 // two-key bracket: this run's values equal to the lower key
     for (uint32_t b = threadIdx.x; b < BINS; b += THREADS) lh[b] = 0;
-    if (threadIdx.x == 0) { lbelow = 0; linb = 0; }
+    if (threadIdx.x == 0) { lbelow = 0; linb = 0; lfirst = 0; }
     __syncthreads();
     // Tiles t0, t0 + step, ... below t1 of array a (whose first tile is a_first).
     auto run = [&](uint32_t a, uint64_t a_first, uint64_t t0, uint64_t t1, uint64_t step) {
         const EncodeJob &job = jobs[a];
         if (job.kind == KIND_U64_PLAIN || job.mode == SEL_DONE) return;  // uniform
         // a histogram-mode array with a tiny bracket counts in per-lane columns (see MICRO_KEYS)
-        const uint32_t mode = job.mode == SEL_BRACKET_HIST && job.hi_b - job.lo_b < (uint64_t)MICRO_KEYS ? SEL_BRACKET_MICRO : job.mode;
+        const uint64_t bspan = job.hi_b - job.lo_b;
+        const uint32_t mode = job.mode != SEL_BRACKET_HIST || bspan >= (uint64_t)MICRO_KEYS ? job.mode
+                              : bspan == 0 ? SEL_BRACKET_ONE : bspan == 1 ? SEL_BRACKET_TWO : SEL_BRACKET_MICRO;
         const void *values = job.values;
         const uint32_t kind = job.kind;
         const uint64_t n = job.n, seg_cap = job.seg_cap;
@@ -571,6 +584,12 @@ __global__ __launch_bounds__(THREADS) void enc_bracket_kernel(EncodeJob *__restr
             } else if (mode == SEL_BRACKET_MICRO) {
                 if (whole) bracket_values<SEL_BRACKET_MICRO, true, 0, 2 * PAIRS>(x, kind, v0, n, lo_b, hi_b, acc, lh, nullptr, nullptr);
                 else bracket_values<SEL_BRACKET_MICRO, false, 0, 2 * PAIRS>(x, kind, v0, n, lo_b, hi_b, acc, lh, nullptr, nullptr);
+            } else if (mode == SEL_BRACKET_ONE) {
+                if (whole) bracket_values<SEL_BRACKET_ONE, true, 0, 2 * PAIRS>(x, kind, v0, n, lo_b, hi_b, acc, lh, nullptr, nullptr);
+                else bracket_values<SEL_BRACKET_ONE, false, 0, 2 * PAIRS>(x, kind, v0, n, lo_b, hi_b, acc, lh, nullptr, nullptr);
+            } else if (mode == SEL_BRACKET_TWO) {
+                if (whole) bracket_values<SEL_BRACKET_TWO, true, 0, 2 * PAIRS>(x, kind, v0, n, lo_b, hi_b, acc, lh, nullptr, nullptr);
+                else bracket_values<SEL_BRACKET_TWO, false, 0, 2 * PAIRS>(x, kind, v0, n, lo_b, hi_b, acc, lh, nullptr, nullptr);
             } else {
                 // a wave appends at most TILE / CAND_PARTS / WAVES values per part of a tile
 #define ZBRA_COMPACT_PART(E0, E1)                                                                                                  \
@@ -606,6 +625,12 @@ __global__ __launch_bounds__(THREADS) void enc_bracket_kernel(EncodeJob *__restr
                 if (above < __hip_atomic_load(pabove, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMin(pabove, (unsigned long long)above);
             }
             if (mode == SEL_BRACKET_COMPACT) flush_wave();
+            if (mode == SEL_BRACKET_TWO) {
+                uint32_t c = acc.first;
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o);
+                if ((threadIdx.x & 63) == 0 && c) atomicAdd(&lfirst, c);
+            }
             if (mode == SEL_BRACKET_MICRO) {  // sum the lanes' private columns into the array's histogram
                 uint32_t *gh = job.hist;
 #pragma unroll
@@ -628,7 +653,13 @@ __global__ __launch_bounds__(THREADS) void enc_bracket_kernel(EncodeJob *__restr
             if (threadIdx.x == 0) {
                 if (lbelow) atomicAdd(&ctr->below, lbelow);
                 if (linb) atomicAdd(&ctr->inb, linb);
-                lbelow = 0; linb = 0;
+                // one- and two-key brackets: the histogram's bins are these counts
+                if (mode == SEL_BRACKET_ONE && linb) atomicAdd(&job.hist[0], (uint32_t)linb);
+                if (mode == SEL_BRACKET_TWO) {
+                    if (lfirst) atomicAdd(&job.hist[0], lfirst);
+                    if (linb - lfirst) atomicAdd(&job.hist[1], (uint32_t)(linb - lfirst));
+                }
+                lbelow = 0; linb = 0; lfirst = 0;
             }
             __syncthreads();
         }
