@@ -501,7 +501,10 @@ __device__ __forceinline__ void bracket_values(const int64_t (&x)[2 * PAIRS], ui
     }
 }
 
-__global__ __launch_bounds__(THREADS) void enc_bracket_kernel(EncodeJob *__restrict__ jobs,
+#ifndef ZBRA_BRACKET_WAVES
+#define ZBRA_BRACKET_WAVES 4
+#endif
+__global__ __launch_bounds__(THREADS, ZBRA_BRACKET_WAVES) void enc_bracket_kernel(EncodeJob *__restrict__ jobs,
                                                                const uint64_t *__restrict__ tile_start, uint32_t nd,
                                                                uint64_t ntiles) {
     // Histogram (exact keys of a narrow bracket; first digit of the keys of a wide one, whose
