@@ -126,24 +126,22 @@ __global__ __launch_bounds__(ENUM_THREADS) void enum_counts_kernel(const uint32_
 // variants: 530 us for the general kernel above (131072 workgroups, each a chain of set-up and
 // load latencies for 8 KiB of tags), 300 us for this one.
 constexpr int ENUM_COUNT_TILES = 2;  // tiles per wave
-__device__ __forceinline__ void enum_count_tag(uint32_t tag, uint64_t row, const uint32_t (&vt)[ENUM_FEW], uint32_t live, uint32_t &lo,
-                                               uint32_t &hi, uint64_t &bad) {
-    bool any = false;
+// A row whose tag no variant carries is not looked for here: it shows afterwards, as a tile whose
+// counts do not add up to its rows, and only then is the tile read again for the row (the common
+// case pays nothing per row for it).
+__device__ __forceinline__ void enum_count_tag(uint32_t tag, const uint32_t (&vt)[ENUM_FEW], uint32_t live, uint32_t &lo, uint32_t &hi) {
 #pragma unroll
     for (int b = 0; b < 4; b++) {
         const bool hit = ((live >> b) & 1u) && tag == vt[b];
         lo += hit ? 1u << (8 * b) : 0u;
-        any = any || hit;
     }
     if (live >> 4) {  // uniform
 #pragma unroll
         for (int b = 4; b < ENUM_FEW; b++) {
             const bool hit = ((live >> b) & 1u) && tag == vt[b];
             hi += hit ? 1u << (8 * (b - 4)) : 0u;
-            any = any || hit;
         }
     }
-    if (!any && row < bad) bad = row;
 }
 __device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v) {
 #pragma unroll
@@ -176,16 +174,15 @@ __global__ __launch_bounds__(ENUM_THREADS) void enum_counts_few_kernel(const uin
             for (int st = 0; st < ENUM_TILE / 256; st++) x[st] = __builtin_nontemporal_load(src + st * 64);
 #pragma unroll
             for (int st = 0; st < ENUM_TILE / 256; st++) {
-                const uint64_t row = r0 + (uint32_t)st * 256u + lane * 4u;
-                enum_count_tag(x[st].x, row, vt, live, lo, hi, bad);
-                enum_count_tag(x[st].y, row + 1, vt, live, lo, hi, bad);
-                enum_count_tag(x[st].z, row + 2, vt, live, lo, hi, bad);
-                enum_count_tag(x[st].w, row + 3, vt, live, lo, hi, bad);
+                enum_count_tag(x[st].x, vt, live, lo, hi);
+                enum_count_tag(x[st].y, vt, live, lo, hi);
+                enum_count_tag(x[st].z, vt, live, lo, hi);
+                enum_count_tag(x[st].w, vt, live, lo, hi);
             }
         } else {
             for (uint32_t st = 0; st < (uint32_t)ENUM_TILE / 64; st++) {
                 const uint64_t row = r0 + st * 64u + lane;
-                if (row < n) enum_count_tag(tags[row], row, vt, live, lo, hi, bad);
+                if (row < n) enum_count_tag(tags[row], vt, live, lo, hi);
             }
         }
         // bytes -> 16-bit fields (a wave's 2048 rows fit), summed over the lanes
@@ -195,6 +192,22 @@ __global__ __launch_bounds__(ENUM_THREADS) void enum_counts_few_kernel(const uin
 #pragma unroll
         for (int b = 0; b < ENUM_FEW; b++)
             if (lane == (uint32_t)b && (uint32_t)b < nv) tile_counts[(uint64_t)b * ntiles + tile] = c[b];
+        uint32_t counted = 0;
+#pragma unroll
+        for (int b = 0; b < ENUM_FEW; b++) counted += c[b];
+        const uint64_t rows = n - r0 < (uint64_t)ENUM_TILE ? n - r0 : (uint64_t)ENUM_TILE;
+        if ((uint64_t)counted != rows) {  // uniform, rare: some row's tag is carried by no variant; find the first
+            for (uint32_t st = 0; st < (uint32_t)ENUM_TILE / 64; st++) {
+                const uint64_t row = r0 + st * 64u + lane;
+                if (row < n && row < bad) {
+                    const uint32_t tag = tags[row];
+                    bool any = false;
+#pragma unroll
+                    for (int b = 0; b < ENUM_FEW; b++) any = any || (((live >> b) & 1u) && tag == vt[b]);
+                    if (!any) bad = row;
+                }
+            }
+        }
     }
     bad = wave_min_u64(bad);
     if (lane == 0 && bad != ~0ull) atomicMin(first_bad_row, (unsigned long long)bad);
