@@ -47,11 +47,24 @@ def make_array(torch, g, dev, kind, n):
         return v
     if kind == "skewed":                       # sample-based brackets see a lopsided distribution
         return (rnd(0, 1 << 20) * rnd(0, 1 << 20)) >> 10
+    if kind == "full64":                       # every bit random: the widest brackets there are
+        return (rnd(-(1 << 62), 1 << 62) << 1) ^ rnd(0, 4)
+    if kind == "three_far":                    # three values far apart: the candidate list overflows
+        return torch.where(rnd(0, 3) == 0, -(1 << 62), torch.where(rnd(0, 2) == 0, 12345, (1 << 62) + 99))
+    if kind == "popular_in_wide":              # a few per cent of one value at the median of wide data
+        v = torch.where(rnd(0, 2) == 0, -rnd(1 << 40, 1 << 62), rnd(1 << 40, 1 << 62))
+        return torch.where(rnd(0, 100) < 3, 12345, v)
+    if kind == "cluster_in_wide":              # a dense cluster of different values at the median of wide data
+        v = torch.where(rnd(0, 2) == 0, -rnd(1 << 40, 1 << 62), rnd(1 << 40, 1 << 62))
+        return torch.where(rnd(0, 100) < 4, 500_000_000 + rnd(0, 5000), v)
+    if kind == "doubles":                      # f64 bit patterns of a normal-ish spread around zero
+        x = (torch.rand(n, device=dev, generator=g, dtype=torch.float64) - 0.5) * 1e6
+        return x.view(torch.int64)
     raise ValueError(kind)
 
 
 KINDS = ["constant", "two", "two_far", "narrow", "wide", "w40", "full", "sorted", "reversed", "sawtooth", "median_run",
-         "outliers", "skewed"]
+         "outliers", "skewed", "full64", "three_far", "popular_in_wide", "cluster_in_wide", "doubles"]
 
 
 def expected(torch, v):
