@@ -10,12 +10,12 @@ out=$root/gpurun_out/${tag}_encode_w${bits}.txt
 d=$(mktemp -d /tmp/prof.XXXXXX)
 export TMPDIR=/tmp
 cd /tmp
-timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d "$d/t" -o t -- python3 "$root/scripts/enc_width_prof.py" "$bits" 27 10 2>/dev/null | tail -1 > "$out"
+timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d "$d/t" -o t -- python3 "$root/scripts/enc_width_prof.py" "$bits" ${ROWS_LOG2:-27} 10 2>/dev/null | tail -1 > "$out"
 if [ -z "$FAST" ]; then  # FAST=1: kernel times only
-timeout -s KILL 120 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$d/f" -o f -- python3 "$root/scripts/enc_width_prof.py" "$bits" 27 2 > /dev/null 2>&1
-timeout -s KILL 120 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$d/w" -o w -- python3 "$root/scripts/enc_width_prof.py" "$bits" 27 2 > /dev/null 2>&1
+timeout -s KILL 120 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$d/f" -o f -- python3 "$root/scripts/enc_width_prof.py" "$bits" ${ROWS_LOG2:-27} 2 > /dev/null 2>&1
+timeout -s KILL 120 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$d/w" -o w -- python3 "$root/scripts/enc_width_prof.py" "$bits" ${ROWS_LOG2:-27} 2 > /dev/null 2>&1
 fi
-python3 - "$d" "$bits" >> "$out" <<'PY'
+python3 - "$d" "$bits" "$out" >> "$out" <<'PY'
 import csv, glob, re, sys
 from collections import defaultdict
 d, bits = sys.argv[1], int(sys.argv[2])
@@ -44,6 +44,9 @@ for k, (calls, us) in sorted(times.items(), key=lambda kv: -kv[1][0] * kv[1][1])
     tot_t += us * mult; tot_r += rd * mult; tot_w += wr * mult
     print("%-34s %6d %10.1f %14.1f %14.1f" % (k[:34], calls, us, rd / 1e6, wr / 1e6))
 print("per encode: kernels %.1f us, HBM read %.1f MB + written %.1f MB = %.1f MB" % (tot_t, tot_r / 1e6, tot_w / 1e6, (tot_r + tot_w) / 1e6))
+algo = re.search(r"algorithmic (\d+) B", open(sys.argv[3]).readline())
+if algo and tot_r + tot_w > 0:
+    print("HBM traffic / algorithmic bytes (two reads of the values + the encoding) = %.3f" % ((tot_r + tot_w) / int(algo.group(1))))
 PY
 rm -rf "$d"
 cat "$out"
