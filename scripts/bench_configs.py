@@ -31,6 +31,9 @@ def timed(fn, reps):
     return e0.elapsed_time(e1) / reps
 
 
+ENCODE_ONLY = False
+
+
 def run_batch(cols, label, reps):
     """cols: list of int64 / int32 tensors.  Batched encode, batched decode, round trip."""
     import torch
@@ -50,6 +53,8 @@ def run_batch(cols, label, reps):
     enc_ms = timed(lambda: device.encode_batch_dev(edesc, res), max(1, reps // 4))
     rs = device.read_results(res)
     assert all(r.status == 0 for r in rs)
+    if ENCODE_ONLY:  # for kernel traces: the last dispatches of the process are one encode
+        return {"case": label, "arrays": len(cols), "encode_ms": round(enc_ms, 4)}
     lens = [int(r.out_count) for r in rs]
     # a round trip succeeds with ANY midpoint: check the medians themselves against a sort
     for i, (c, r) in enumerate(zip(cols, rs)):
@@ -88,7 +93,11 @@ def main():
     ap.add_argument("--config", type=int, nargs="+", default=[3, 4])
     ap.add_argument("--scale-log2", type=int, default=0, help="divide the row counts by 2^this (smoke runs)")
     ap.add_argument("--reps", type=int, default=10)
+    ap.add_argument("--encode-only", action="store_true", help="no median check, no decode (kernel traces)")
+    ap.add_argument("--only", choices=["a", "b"], help="config 4: only the clustered (a) or only the time-series (b) Int columns")
     args = ap.parse_args()
+    global ENCODE_ONLY
+    ENCODE_ONLY = args.encode_only
     import torch
     import torch.distributed as dist
 
@@ -116,9 +125,11 @@ def main():
             t, variants = workloads.enum_block(b, 1 << 22, dev)
             tags.append(t)
             for _, a, bcol in variants:
-                ints += [a, bcol]
+                ints += [a, bcol] if not args.only else [a] if args.only == "a" else [bcol]
         print(json.dumps(run_batch(tags, "config 4 (one GPU's 2^29 rows): enum tags -> u32, %d Blocks" % blocks, args.reps)), flush=True)
         print(json.dumps(run_batch(ints, "config 4: Int columns of the variants, %d arrays" % len(ints), args.reps)), flush=True)
+        if args.only:
+            return
         if world > 1:
             dist.barrier()
         both = run_batch(tags + ints, "config 4: tags + Int columns in one submission", args.reps)

@@ -10,6 +10,7 @@ import csv, glob, sys
 f = glob.glob(sys.argv[1] + "/**/*kernel_stats.csv", recursive=True)[0]
 for r in csv.DictReader(open(f)):
     if "zbra" in r["Name"]:
-        print("  %-52s %4s x %9.1f us" % (r["Name"].split("(")[0][:52], r["Calls"], float(r["AverageNs"]) / 1000))
+        print("  %-52s %4s x %9.1f us  (min %9.1f, max %9.1f)" % (r["Name"].split("(")[0][:52], r["Calls"], float(r["AverageNs"]) / 1000,
+                                                                   float(r["MinNs"]) / 1000, float(r["MaxNs"]) / 1000))
 PY
 rm -rf "$d"

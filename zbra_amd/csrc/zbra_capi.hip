@@ -212,7 +212,7 @@ static int decode_batch_dev(DeviceCtx *ctx, const zbra_array_desc *descs, size_t
     for (size_t i = 0; i < nd; i++) ntiles += decode_tiles_of(descs[i].count, descs[i].kind);
     const size_t total = off_map + ntiles * sizeof(uint32_t);  // the map lives on the device only
     Slot *s;
-    ZBRA_TRY(ctx->acquire(total, &s, 0, off_ts + (nd + 1) * sizeof(uint64_t)));  // plans and the map live on the device only
+    ZBRA_TRY(ctx->acquire(total, &s, off_ts + (nd + 1) * sizeof(uint64_t)));  // plans and the map live on the device only
     std::memcpy(s->host, descs, nd * sizeof(zbra_array_desc));
     uint64_t *h_ts = (uint64_t *)((char *)s->host + off_ts);
     uint64_t run = 0;
@@ -357,8 +357,16 @@ static int encode_batch_dev(DeviceCtx *ctx, const EncodeItem *items, size_t nd, 
     const size_t off_lvl = off_ctr + (size_t)n_list * sizeof(BracketCounters);
     const size_t off_pend = off_lvl + (size_t)n_big * SEL_LEVELS * BINS * sizeof(uint32_t);
     const size_t total = off_pend + ((size_t)n_big + 1) * sizeof(uint32_t);
+    // candidate lists and gathered keys live in the stream's scratch buffer: this call's kernels
+    // follow the previous call's in stream order, and the lock keeps another thread's enqueues on
+    // the same stream from interleaving with them
+    StreamScratch *ss;
+    ZBRA_TRY(ctx->lock_scratch_of(stream, &ss));
+    std::lock_guard<std::mutex> scratch_guard(ss->mu, std::adopt_lock);
+    ZBRA_TRY(DeviceCtx::grow_scratch(ss, scratch_bytes));
+    char *scratch = (char *)ss->mem.ptr;
     Slot *s;
-    ZBRA_TRY(ctx->acquire(total, &s, scratch_bytes, host_bytes));
+    ZBRA_TRY(ctx->acquire(total, &s, host_bytes));
     EncodeJob *h_jobs = (EncodeJob *)s->host;
     uint64_t *h_ts = (uint64_t *)((char *)s->host + off_ts);
     uint32_t *h_list = (uint32_t *)((char *)s->host + off_list);
@@ -374,7 +382,7 @@ static int encode_batch_dev(DeviceCtx *ctx, const EncodeItem *items, size_t nd, 
         j.sel_values = items[i].values; j.sel_n = items[i].n; j.sel_kind = items[i].kind;
         j.seg_cap = seg_cap_of(items[i]);
         if (j.seg_cap) {
-            j.cand = (int64_t *)((char *)s->scratch + scratch_off);
+            j.cand = (int64_t *)(scratch + scratch_off);
             scratch_off += j.seg_cap * CAND_SEGS * sizeof(int64_t);
         }
         if (listed(items[i])) {
@@ -383,7 +391,7 @@ static int encode_batch_dev(DeviceCtx *ctx, const EncodeItem *items, size_t nd, 
             h_list[i_list++] = (uint32_t)i;
             if (is_long(items[i])) {
                 j.lvl_hist = (uint32_t *)((char *)s->dev + off_lvl) + (size_t)i_big * SEL_LEVELS * BINS;
-                j.small = (uint64_t *)((char *)s->scratch + off_small) + (size_t)i_big * GATHER_CAP;
+                j.small = (uint64_t *)(scratch + off_small) + (size_t)i_big * GATHER_CAP;
                 i_big++;
             }
         }
@@ -408,10 +416,11 @@ static int encode_batch_dev(DeviceCtx *ctx, const EncodeItem *items, size_t nd, 
         // workgroups of a many-workgroup select level, dealt to the arrays it finds pending
         static const unsigned level_grid = [] { const char *e = getenv("ZBRA_HIP_LEVEL_GRID"); return e ? (unsigned)atol(e) : 0u; }();
         static const unsigned sparse_tiles = [] { const char *e = getenv("ZBRA_HIP_SPARSE_TILES"); return e ? (unsigned)atol(e) : 0u; }();
-        // 512 workgroups per array that may be pending, up to 4096 (8192 for many): a single 2^27-row
-        // column with a wide bracket encodes in 0.569 ms with 512, 0.582 with 1024 or 256, 0.596 with
-        // 4096 (most of a large grid only passes through, behind the workgroups that work)
-        const unsigned gh = level_grid ? level_grid : n_big >= 512 ? 8192u : n_big >= 8 ? 4096u : 512u * n_big;
+        // 512 workgroups per array that may be pending, up to 2048: a single 2^27-row column with a
+        // wide bracket encodes in 0.569 ms with 512, 0.582 with 1024 or 256, 0.596 with 4096 (most of
+        // a large grid only passes through, behind the workgroups that work); a thousand arrays
+        // take 1024, 2048, 4096 or 8192 alike within 3 % (scripts/sweep_level_grid_batches.sh)
+        const unsigned gh = level_grid ? level_grid : n_big >= 4 ? 2048u : 512u * n_big;
         if (ntiles) {
             hipLaunchKernelGGL(enc_sample_kernel, dim3((unsigned)nd), dim3(SAMPLE_THREADS), 0, stream, d_jobs, (uint32_t)nd,
                                bracket ? 1u : 0u);
@@ -931,7 +940,7 @@ int zbra_hip_decode_offsets_dev(const uint8_t *d_data, size_t len, size_t count,
     const uint64_t ntiles = ((uint64_t)count + OFF_TILE - 1) / OFF_TILE;
     const uint64_t nchunks = (ntiles + SCAN_CHUNK - 1) / SCAN_CHUNK;
     Slot *s;
-    ZBRA_TRY(ctx->acquire(128 + (size_t)(ntiles + nchunks + 1) * sizeof(uint64_t), &s, 0, 64));  // nothing comes from the host
+    ZBRA_TRY(ctx->acquire(128 + (size_t)(ntiles + nchunks + 1) * sizeof(uint64_t), &s, 64));  // nothing comes from the host
     DecodePlan *plan = (DecodePlan *)s->dev;
     uint64_t *tile_start = (uint64_t *)((char *)s->dev + 64);  // written by the plan kernel, not used here
     uint64_t *tile_sums = (uint64_t *)((char *)s->dev + 128);
@@ -964,7 +973,7 @@ int zbra_hip_enum_rows_dev(const uint32_t *d_tags, size_t n, const uint32_t *var
     const uint64_t nchunks = (ntiles + SCAN_CHUNK - 1) / SCAN_CHUNK;
     const size_t off_bad = ENUM_MAX_VARIANTS * sizeof(uint32_t), off_counts = 256;
     Slot *s;
-    ZBRA_TRY(ctx->acquire(off_counts + (size_t)n_variants * (ntiles + nchunks) * sizeof(uint64_t), &s, 0, off_bad));
+    ZBRA_TRY(ctx->acquire(off_counts + (size_t)n_variants * (ntiles + nchunks) * sizeof(uint64_t), &s, off_bad));
     uint32_t *h_vt = (uint32_t *)s->host;
     for (uint32_t v = 0; v < (uint32_t)ENUM_MAX_VARIANTS; v++) h_vt[v] = v < n_variants ? variant_tags[v] : 0;
     const uint32_t *d_vt = (const uint32_t *)s->dev;

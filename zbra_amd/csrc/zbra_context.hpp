@@ -38,8 +38,6 @@ struct Slot {
     void *dev = nullptr;
     size_t cap = 0;       // of dev
     size_t host_cap = 0;  // of host
-    void *scratch = nullptr;  // device-only memory of the borrower (candidate lists of an encode)
-    size_t scratch_cap = 0;
     hipEvent_t done = nullptr;
     bool busy = false;  // between acquire() and release()
 };
@@ -55,6 +53,16 @@ struct Arena {
 struct FileLane {
     hipStream_t stream = nullptr;
     Arena img, res;
+};
+
+// Device-only memory that the kernels of ONE stream's calls pass through in stream order (the
+// candidate lists of an encode): one buffer per stream serves every call on it, where a buffer per
+// call in flight meant a fresh multi-GiB allocation whenever a caller ran ahead of the device.
+struct StreamScratch {
+    hipStream_t stream = nullptr;
+    Arena mem;
+    std::mutex mu;       // held while a call enqueues: kernels of two calls that share the buffer must not interleave
+    uint64_t used = 0;   // tick of the last use (guarded by DeviceCtx::mu)
 };
 
 struct DeviceCtx {
@@ -78,9 +86,8 @@ struct DeviceCtx {
     HostPipe pipe_up;           // uploads issued while `pipe` is busy with the way back (piecewise decode)
 
     // A slot whose device buffer holds `bytes` and whose pinned host buffer holds `host_bytes`
-    // (0 = as large as the device buffer: only the part the host fills needs a pinned twin);
-    // scratch_bytes of further device-only memory come with it (grown while the slot is idle).
-    int acquire(size_t bytes, Slot **out, size_t scratch_bytes = 0, size_t host_bytes = 0) {
+    // (0 = as large as the device buffer: only the part the host fills needs a pinned twin).
+    int acquire(size_t bytes, Slot **out, size_t host_bytes = 0) {
         if (host_bytes == 0 || host_bytes > bytes) host_bytes = bytes;
         std::lock_guard<std::mutex> g(mu);
         Slot *small = nullptr;  // an idle slot that is too small: regrown rather than left behind
@@ -91,12 +98,6 @@ struct DeviceCtx {
                 continue;
             }
             if (s->cap < bytes || s->host_cap < host_bytes) { small = s; continue; }
-            if (s->scratch_cap < scratch_bytes) {
-                if (s->scratch) ZBRA_HIP_TRY(hipFree(s->scratch));
-                s->scratch = nullptr; s->scratch_cap = 0;
-                ZBRA_HIP_TRY(hipMalloc(&s->scratch, scratch_bytes));
-                s->scratch_cap = scratch_bytes;
-            }
             s->busy = true;
             *out = s;
             return ZBRA_OK;
@@ -108,20 +109,14 @@ struct DeviceCtx {
         if (!fresh) {  // everything enqueued with it has run (its event says so)
             if (s->cap < cap) { (void)hipFree(s->dev); s->dev = nullptr; s->cap = 0; }
             if (s->host_cap < hcap) { (void)hipHostFree(s->host); s->host = nullptr; s->host_cap = 0; }
-            if (s->scratch_cap < scratch_bytes && s->scratch) { (void)hipFree(s->scratch); s->scratch = nullptr; s->scratch_cap = 0; }
         }
         if (!s->host) { e = hipHostMalloc(&s->host, hcap, hipHostMallocDefault); if (e == hipSuccess) s->host_cap = hcap; }
         if (e == hipSuccess && !s->dev) { e = hipMalloc(&s->dev, cap); if (e == hipSuccess) s->cap = cap; }
-        if (e == hipSuccess && scratch_bytes && !s->scratch) {
-            e = hipMalloc(&s->scratch, scratch_bytes);
-            if (e == hipSuccess) s->scratch_cap = scratch_bytes;
-        }
         if (e == hipSuccess && !s->done) e = hipEventCreateWithFlags(&s->done, hipEventDisableTiming);
         if (e != hipSuccess) {
             if (fresh) {
                 if (s->host) (void)hipHostFree(s->host);
                 if (s->dev) (void)hipFree(s->dev);
-                if (s->scratch) (void)hipFree(s->scratch);
                 delete s;
             }  // a regrown slot stays in the list with whatever buffers it still has (caps say which)
             return hip_status(e);
@@ -130,6 +125,55 @@ struct DeviceCtx {
         if (fresh) slots.push_back(s);
         *out = s;
         return ZBRA_OK;
+    }
+
+    // The scratch buffer of `stream` (created on first use), returned with its mutex HELD: unlock
+    // it when the call's last kernel is enqueued.  At most MAX_STREAM_SCRATCH streams keep a buffer:
+    // beyond that the least recently used one that nobody holds is handed over, once the device
+    // has finished what was enqueued (streams come and go in a long-lived process).
+    static constexpr size_t MAX_STREAM_SCRATCH = 16;
+    std::vector<StreamScratch *> stream_scratch;
+    uint64_t scratch_tick = 0;
+    int lock_scratch_of(hipStream_t stream, StreamScratch **out) {
+        for (;;) {
+            StreamScratch *found = nullptr;
+            {
+                std::lock_guard<std::mutex> g(mu);
+                for (StreamScratch *ss : stream_scratch)
+                    if (ss->stream == stream) { found = ss; break; }
+                if (!found && stream_scratch.size() >= MAX_STREAM_SCRATCH) {
+                    StreamScratch *victim = nullptr;
+                    for (StreamScratch *ss : stream_scratch)
+                        if (!victim || ss->used < victim->used) victim = ss;
+                    if (victim->mu.try_lock()) {  // nobody is enqueueing with it
+                        const hipError_t e = hipDeviceSynchronize();
+                        if (e != hipSuccess) { victim->mu.unlock(); return hip_status(e); }
+                        if (victim->mem.ptr) (void)hipFree(victim->mem.ptr);
+                        victim->mem = Arena();
+                        victim->stream = stream;
+                        victim->used = ++scratch_tick;
+                        *out = victim;
+                        return ZBRA_OK;
+                    }
+                }
+                if (!found) {
+                    found = new StreamScratch();
+                    found->stream = stream;
+                    stream_scratch.push_back(found);
+                }
+                found->used = ++scratch_tick;
+            }
+            // not under `mu`: whoever holds the buffer's mutex takes `mu` for its workspace slot
+            found->mu.lock();
+            if (found->stream == stream) { *out = found; return ZBRA_OK; }
+            found->mu.unlock();  // handed over to another stream in between: look again
+        }
+    }
+    // Call with ss->mu held.  Growing waits for the stream: its earlier calls read the old buffer.
+    static int grow_scratch(StreamScratch *ss, size_t bytes) {
+        if (ss->mem.cap >= bytes) return ZBRA_OK;
+        ZBRA_HIP_TRY(hipStreamSynchronize(ss->stream));
+        return grow_dev(ss->mem, bytes);
     }
 
     // Call after the last use of the slot has been enqueued on `stream`.

@@ -305,7 +305,8 @@ struct SampleShared {
     uint32_t hist[2][BINS];
     uint64_t wave_lo[SAMPLE_THREADS / 64], wave_hi[SAMPLE_THREADS / 64];
     uint32_t wave_sum[2][SAMPLE_THREADS / 64];
-    uint32_t bin[2], before[2];
+    uint32_t bin[2], before[2], cnt[2];
+    uint64_t found[2];
 };
 // key[i] valid for i < nvalid (this lane's keys); ranks r0 <= r1 < total valid keys.  Returns the
 // keys of rank r0 and r1 in out[0], out[1], the smallest and largest key in out[2], out[3].  Every
@@ -361,7 +362,7 @@ __device__ __forceinline__ void select_two_ranks(const uint64_t (&key)[SAMPLE_PE
                 uint32_t run = before;
 #pragma unroll
                 for (int q = 0; q < BINS / SAMPLE_THREADS; q++) {
-                    if (k[h] >= run && k[h] < run + c[h][q]) { sh->bin[h] = tid * (BINS / SAMPLE_THREADS) + q; sh->before[h] = run; }
+                    if (k[h] >= run && k[h] < run + c[h][q]) { sh->bin[h] = tid * (BINS / SAMPLE_THREADS) + q; sh->before[h] = run; sh->cnt[h] = c[h][q]; }
                     run += c[h][q];
                 }
             }
@@ -373,9 +374,24 @@ __device__ __forceinline__ void select_two_ranks(const uint64_t (&key)[SAMPLE_PE
             prefix[h] = (lv == 0 ? 0 : prefix[h] << d) | (sh->bin[h] & ((1u << d) - 1u));
             k[h] -= sh->before[h];
         }
+        // Keys spread over a wide range are alone in their bin after a pass or two (4096 keys in
+        // 4096 bins): the one key that carries each prefix is the answer, its lower digits need
+        // no passes of their own.
+        const bool alone = sh->cnt[0] == 1 && sh->cnt[1] == 1 && lv + 1 < passes;  // uniform
+        if (alone) {
+#pragma unroll
+            for (int i = 0; i < SAMPLE_PER; i++) {
+                if ((uint32_t)i < nvalid) {
+                    const uint64_t rel = key[i] - lo;
+                    if ((rel >> shift) == prefix[0]) sh->found[0] = rel;
+                    if ((rel >> shift) == prefix[1]) sh->found[1] = rel;
+                }
+            }
+        }
         // the next pass's zeroing of the histograms comes after every lane has read bin / before:
         // the barrier at the top of its counting loop is behind the zeroing, so add one here
         __syncthreads();
+        if (alone) { prefix[0] = sh->found[0]; prefix[1] = sh->found[1]; break; }
     }
     out[0] = lo + prefix[0];
     out[1] = lo + prefix[1];
@@ -432,6 +448,7 @@ __global__ __launch_bounds__(SAMPLE_THREADS) void enc_sample_kernel(EncodeJob *_
     const bool has_lo = r >= (uint64_t)margin, has_hi = r + margin < (uint64_t)sample;
     select_two_ranks(key, nvalid, has_lo ? (uint32_t)(r - margin) : 0u, has_hi ? (uint32_t)(r + margin) : sample - 1, &sh, got);
     if (threadIdx.x != 0) return;
+    job.min_b = got[2]; job.max_b = got[3];  // of the sample: where the bracket pass's minimum and maximum start
     job.lo_b = has_lo ? got[0] : 0;
     job.hi_b = has_hi ? got[1] : ~0ull;
     job.key_base = job.lo_b;  // keys of a bracket select: (v ^ SIGN) - lo_b
@@ -464,16 +481,51 @@ constexpr uint32_t SEL_BRACKET_ONE = 101, SEL_BRACKET_TWO = 102;  // template ta
 
 // Values x[E0..E1) of a tile.  MODE and WHOLE (the tile lies wholly inside the array) are
 // compile-time so that the loop body is straight-line code with one branch (the append).
+//
+// Minimum and maximum: a 64-bit min / max is a compare and two selects each, per value, although
+// after a lane's first few values hardly any value improves on what it holds (it starts from the
+// sample's extremes).  So the wave first asks whether ANY lane has such a value (two compares and
+// a scalar branch) and only then updates.
 template <uint32_t MODE, bool WHOLE, int E0, int E1>
 __device__ __forceinline__ void bracket_values(const int64_t (&x)[2 * PAIRS], uint32_t kind, uint64_t v0, uint64_t n, uint64_t lo_b,
                                                uint64_t hi_b, BracketAcc &acc, uint32_t *lh, int64_t *lcand, uint32_t *lcount,
-                                               uint32_t digit_shift = 0) {
+                                               uint32_t digit_shift = 0, uint32_t *wave_cnt = nullptr) {
+    // lanes past the end hold a value of the array: harmless here
+    uint64_t improves = 0;  // uniform: lanes with a value beyond what they hold
 #pragma unroll
     for (int e = E0; e < E1; ++e) {
         const uint64_t b = (uint64_t)x[e] ^ SIGN;
-        acc.lo = min(acc.lo, b);  // lanes past the end hold a value of the array: harmless here
-        acc.hi = max(acc.hi, b);
-        if (MODE != SEL_FULL) {
+        improves |= __builtin_amdgcn_ballot_w64(b < acc.lo) | __builtin_amdgcn_ballot_w64(b > acc.hi);
+    }
+    if (improves != 0) {
+        asm volatile("" ::: "memory");  // keeps this a branch: as straight-line selects it costs more than it saves
+#pragma unroll
+        for (int e = E0; e < E1; ++e) {
+            const uint64_t b = (uint64_t)x[e] ^ SIGN;
+            acc.lo = min(acc.lo, b);
+            acc.hi = max(acc.hi, b);
+        }
+    }
+#pragma unroll
+    for (int e = E0; e < E1; ++e) {
+        const uint64_t b = (uint64_t)x[e] ^ SIGN;
+        if (MODE == SEL_BRACKET_COMPACT) {
+            // Wide bracket.  Counts are kept per WAVE, from the ballots (scalar unit), and the
+            // smallest value above the bracket is not looked for: an upper median that is not
+            // inside the bracket sends the array to the select over all its values.
+            const bool valid = WHOLE || v0 + tile_slot(kind, e) < n;
+            const uint64_t r = b - lo_b;
+            const bool inside = valid && r <= hi_b - lo_b;
+            const uint64_t m = __builtin_amdgcn_ballot_w64(inside);
+            wave_cnt[0] += (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(valid && b < lo_b));
+            wave_cnt[1] += (uint32_t)__popcll(m);
+            if (inside) {
+                // wave-private staging: the ballot gives every lane its slot, no atomic, no barrier
+                lcand[*lcount + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u))] = x[e];
+                atomicAdd(&lh[(uint32_t)(r >> digit_shift)], 1u);  // first digit of the select's key
+            }
+            *lcount += (uint32_t)__popcll(m);
+        } else if (MODE != SEL_FULL) {
             const bool valid = WHOLE || v0 + tile_slot(kind, e) < n;
             const bool is_below = valid && b < lo_b, is_above = valid && b > hi_b;
             const bool inside = valid && !is_below && !is_above;
@@ -486,14 +538,6 @@ __device__ __forceinline__ void bracket_values(const int64_t (&x)[2 * PAIRS], ui
                 acc.first += inside && b == lo_b;
             } else if (MODE == SEL_BRACKET_MICRO) {
                 if (inside) lh[((uint32_t)(b - lo_b) & (MICRO_KEYS - 1)) * THREADS + threadIdx.x] += 1u;
-            } else if (MODE == SEL_BRACKET_COMPACT) {
-                // wave-private staging: the ballot gives every lane its slot, no atomic, no barrier
-                const uint64_t m = __ballot(inside);
-                if (inside) {
-                    lcand[*lcount + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u))] = x[e];
-                    atomicAdd(&lh[(uint32_t)((b - lo_b) >> digit_shift)], 1u);  // first digit of the select's key
-                }
-                *lcount += (uint32_t)__popcll(m);
             } else if (inside) {
                 atomicAdd(&lh[(uint32_t)(b - lo_b)], 1u);
             }
@@ -534,6 +578,9 @@ __global__ __launch_bounds__(THREADS, ZBRA_BRACKET_WAVES) void enc_bracket_kerne
         const uint64_t lo_b = job.lo_b, hi_b = job.hi_b;
         const int64_t fill = load_value(job, 0);  // a value of the array: a no-op for min and max
         BracketAcc acc;
+        // the sample's extremes, or what other workgroups have found since: values of the array
+        acc.lo = __hip_atomic_load(&job.min_b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        acc.hi = __hip_atomic_load(&job.max_b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         // Candidates are staged per WAVE: a quarter of the pool each, filled in ballot order and
         // flushed (one returning atomic on the segment's counter, then a copy by the wave's 64
         // lanes) when less than half a tile's worth of room is left.  No lane of another wave is
@@ -545,6 +592,7 @@ __global__ __launch_bounds__(THREADS, ZBRA_BRACKET_WAVES) void enc_bracket_kerne
         const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
         int64_t *wstage = lcand + wave * WAVE_CAP;
         uint32_t wcount = 0;  // uniform within the wave
+        uint32_t wcnt[2] = {0, 0};  // wide bracket: the wave's values below / inside the bracket
         auto flush_wave = [&]() {
             if (wcount == 0) return;
             const uint32_t sgm = (blockIdx.x * WAVES + wave + flushes++) % CAND_SEGS;
@@ -597,8 +645,8 @@ __global__ __launch_bounds__(THREADS, ZBRA_BRACKET_WAVES) void enc_bracket_kerne
                 // a wave appends at most TILE / CAND_PARTS / WAVES values per part of a tile
 #define ZBRA_COMPACT_PART(E0, E1)                                                                                                  \
     if (wcount + TILE / CAND_PARTS / WAVES > WAVE_CAP) flush_wave();                                                                \
-    if (whole) bracket_values<SEL_BRACKET_COMPACT, true, E0, E1>(x, kind, v0, n, lo_b, hi_b, acc, lh, wstage, &wcount, dsh);       \
-    else bracket_values<SEL_BRACKET_COMPACT, false, E0, E1>(x, kind, v0, n, lo_b, hi_b, acc, lh, wstage, &wcount, dsh);
+    if (whole) bracket_values<SEL_BRACKET_COMPACT, true, E0, E1>(x, kind, v0, n, lo_b, hi_b, acc, lh, wstage, &wcount, dsh, wcnt); \
+    else bracket_values<SEL_BRACKET_COMPACT, false, E0, E1>(x, kind, v0, n, lo_b, hi_b, acc, lh, wstage, &wcount, dsh, wcnt);
                 if (CAND_PARTS == 4) {
                     ZBRA_COMPACT_PART(0, 2)
                     ZBRA_COMPACT_PART(2, 4)
@@ -620,6 +668,7 @@ __global__ __launch_bounds__(THREADS, ZBRA_BRACKET_WAVES) void enc_bracket_kerne
             if (hi > __hip_atomic_load(pmax, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(pmax, (unsigned long long)hi);
         }
         if (mode != SEL_FULL) {
+            if (mode == SEL_BRACKET_COMPACT && lane == 0) { acc.below = wcnt[0]; acc.inb = wcnt[1]; }
             if (acc.below) atomicAdd(&lbelow, (unsigned long long)acc.below);
             if (acc.inb) atomicAdd(&linb, (unsigned long long)acc.inb);
             const uint64_t above = wave_min_u64(acc.above);
@@ -820,7 +869,10 @@ __global__ __launch_bounds__(THREADS) void enc_setup_kernel(EncodeJob *__restric
             // value above it).  The bracket pass has then counted the first digit of the keys inside
             // it (every digit there is, for a narrow bracket), whether or not the candidate list is
             // whole.
-            const bool ok = j.mode != SEL_FULL && k >= j.below && k < j.below + j.inb;
+            // A wide bracket's pass does not look for the smallest value above the bracket: there
+            // both ranks must be inside.
+            const uint64_t k_hi = j.mode == SEL_BRACKET_COMPACT && (j.n & 1) == 0 ? k + 1 : k;
+            const bool ok = j.mode != SEL_FULL && k >= j.below && k_hi < j.below + j.inb;
             if (ok) {
                 // key_base = lo_b and passes were set with the bracket, by the sample kernel
                 if (j.next_above != ~0ull) j.next_above -= j.key_base;  // into key space
@@ -917,7 +969,7 @@ __device__ __forceinline__ void level_one(EncodeJob *__restrict__ jobs, uint32_t
     // A digit counted among keys that share earlier digits, and a gather, touch few counters:
     // nothing to merge, so every workgroup is worth having.
     const bool sparse = s0.action == ACT_HIST || s0.lv > 0;
-    if (sparse) tiles_per_wg = sparse_tiles ? sparse_tiles : tiles_per_wg == 0 ? 8u : 2u;  // few arrays / many (measured: 1, 2, 4, 8, 16 tiles)
+    if (sparse) tiles_per_wg = sparse_tiles ? sparse_tiles : tiles_per_wg == 0 ? 8u : 16u;  // few arrays / many (measured: 2 to 32 tiles)
     else if (tiles_per_wg == 0) tiles_per_wg = work_tiles >= 4096 ? 16u : work_tiles < 512 ? 2u : (uint32_t)(work_tiles / 256);
     const uint64_t want = work_tiles / tiles_per_wg;
     const uint32_t eff = want < 1 ? 1u : want < per_array ? (uint32_t)want : per_array;
@@ -952,6 +1004,11 @@ __device__ __forceinline__ void level_one(EncodeJob *__restrict__ jobs, uint32_t
     static_assert(GATHER_CAP * sizeof(uint64_t) <= BINS * sizeof(uint32_t), "gathered keys are staged in the histogram's LDS");
     uint64_t *stage = (uint64_t *)lh;
     __shared__ uint32_t stage_n, stage_base;
+    // How far each segment of the candidate list is filled.  The loop below asks for every slot it
+    // looks at, most of them empty: from global memory that was a dependent load per slot, and
+    // noticeable when a thousand short lists are pending.
+    __shared__ uint64_t seg_fill[CAND_SEGS];
+    if (from_list && tid < (uint32_t)CAND_SEGS) seg_fill[tid] = job.counters->slot[tid].cand_count;
     __syncthreads();  // the previous item's merge, and this item's pick, have read LDS
     if (gather) { if (tid == 0) stage_n = 0; }
     else for (uint32_t b = tid; b < BINS; b += THREADS) lh[b] = 0;
@@ -1016,7 +1073,7 @@ __device__ __forceinline__ void level_one(EncodeJob *__restrict__ jobs, uint32_t
             for (int q = 0; q < LEVEL_AHEAD; q++) { t0[q] = 0; end[q] = 0; }
             while (m < LEVEL_AHEAD && u < slots) {
                 const uint64_t sgm = u % CAND_SEGS, first = sgm * seg_cap + (u / CAND_SEGS) * TILE;
-                const uint64_t last = sgm * seg_cap + job.counters->slot[sgm].cand_count;  // values exist below this index
+                const uint64_t last = sgm * seg_cap + seg_fill[sgm];  // values exist below this index
                 u += eff;
                 if (first >= last) continue;
 #pragma unroll
