@@ -11,21 +11,22 @@
 //                                                   wrap-around possible), else from an OR pass
 //   4. the packed stream.
 // Selection reads the array ONCE in the common case:
-//   sample   4096 pseudo-randomly placed values are sorted in LDS; the values 192 sample ranks
-//            either side of the median's expected sample rank (6 sigma) bracket the median.
-//            Arrays of up to 4096 values are sorted whole: a, b, min and max fall out directly.
-//   bracket  one pass counts the values below the bracket, finds min / max and the smallest value
-//            above the bracket, and keeps what is inside it: as a histogram when the bracket spans
-//            fewer than 4096 distinct keys, else as a compacted list (about 9 % of the array).
+//   sample   4096 values at hashed positions (one per n/4096 stride) stay in the registers of one
+//            workgroup, which finds the two values 128 sample ranks (4 sigma) either side of the
+//            median's expected sample rank by a two-rank radix select: they bracket the median.
+//            Arrays of up to 4096 values are selected whole: a, b, min and max fall out directly.
+//   bracket  one pass counts the values below the bracket, finds min / max and keeps what is
+//            inside the bracket: as a histogram when it spans fewer than 4096 distinct keys (one or
+//            two counters for a bracket of one or two keys), else as a compacted list (about 6 %
+//            of the array) together with a histogram of the keys' first digit.
 //   verify   the exact counts say whether ranks (n-1)/2 and n/2 are inside the bracket.  If so the
 //            radix select below runs on the histogram / the compacted list; if not (a sample that
 //            misled, more than n/4 candidates) it runs on the whole array, as it would without
 //            the sample.  Either way the result is exact.
-//   select   radix select on key = v - base, 12 bits a digit.  The bracket pass itself counts the
-//            first digit of a wide bracket; a short source is finished by one workgroup in one
-//            launch; a long one gets up to three launches of many workgroups, each of which either
-//            counts the next digit or, as soon as at most 2048 keys share the resolved digits,
-//            gathers those keys for the finishing workgroup to sort.
+//   select   radix select on key = v - base, 12 bits a digit, from the top.  A short source is
+//            finished by one workgroup in one launch; a long one gets up to three launches of many
+//            workgroups, each of which either counts the next digit or, as soon as at most 2048
+//            keys share the resolved digits, gathers those keys for the finishing workgroup to sort.
 // Every kernel works on a whole submission (many arrays) through the same tile -> array map the
 // decoder uses, and every pass that an array does not need skips that array's memory.
 #pragma once
@@ -118,8 +119,8 @@ enum SelectMode : uint32_t {
     SEL_DONE = 3             // midpoint and width already known (small array sorted whole, constant, ...)
 };
 
-constexpr int SAMPLE = 4096;          // sample keys sorted in LDS (32 KiB)
-constexpr int SAMPLE_THREADS = 1024;  // lanes of the sorting workgroup
+constexpr int SAMPLE = 4096;          // sample keys of an array (four per lane of the sampling workgroup)
+constexpr int SAMPLE_THREADS = 1024;  // lanes of the sampling workgroup
 constexpr int SAMPLE_MARGIN = 128;    // sample ranks either side: 4 sigma, sigma = sqrt(SAMPLE)/2 = 32
 constexpr int CAND_DIV = 4;           // candidate list capacity = n / CAND_DIV (a bracket holds ~6 % of n)
 #ifndef ZBRA_CAND_LDS
