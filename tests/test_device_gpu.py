@@ -236,8 +236,8 @@ def test_decode_garbage_never_reads_or_writes_outside(env):
 
 def test_dev_calls_from_threads_on_own_streams(env):
     """Stream-ordered calls may be issued from several threads on different streams: each borrows
-    its own workspace slot (descriptor tables, candidate lists), so concurrent submissions must
-    not see each other's state."""
+    its own workspace slot (descriptor tables, histograms) and every stream has its own scratch
+    buffer (candidate lists), so concurrent submissions must not see each other's state."""
     import threading
     torch, device, oc, L = env
     kinds = ["narrow", "w31", "full", "small_signed", "w40", "binary"]
@@ -271,6 +271,44 @@ def test_dev_calls_from_threads_on_own_streams(env):
     for t in ts:
         t.join()
     assert not errs, errs
+
+
+def test_dev_encodes_from_threads_on_one_stream(env):
+    """Encodes enqueued on ONE stream share that stream's scratch buffer (candidate lists of the
+    median selection); the library serialises their enqueueing, so calls from several threads on
+    the same stream still give exact results, each in its own output.  Sizes differ so that the
+    buffer is regrown while other threads use the stream."""
+    import threading
+    torch, device, oc, L = env
+    kinds = ["w31", "full", "w40", "narrow"]
+    sizes = [300_001, 1_200_003, 150_000, 2_000_001]
+    cols = [column(k, n, 90 + i) for i, (k, n) in enumerate(zip(kinds, sizes))]
+    want = [oc.compress_int_array(c) for c in cols]
+    st = torch.cuda.Stream()
+    vs = [torch.from_numpy(c).cuda() for c in cols]
+    encs = [torch.zeros(device.encode_bound(c.size), dtype=torch.uint8, device="cuda") for c in cols]
+    ress = [device.new_results(1, "cuda") for _ in cols]
+    torch.cuda.synchronize()
+    errs = []
+
+    def work(i):
+        try:
+            for _ in range(10):
+                device.encode_dev(vs[i], encs[i], ress[i], stream=st)
+        except Exception as ex:  # noqa: BLE001
+            errs.append((i, repr(ex)))
+
+    ts = [threading.Thread(target=work, args=(i,)) for i in range(len(cols))]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    st.synchronize()
+    assert not errs, errs
+    for i in range(len(cols)):
+        r = device.read_results(ress[i])[0]
+        assert r.status == 0 and r.out_count == len(want[i]), (i, r)
+        assert encs[i][:len(want[i])].cpu().numpy().tobytes() == want[i], i
 
 
 @pytest.mark.parametrize("dtype_name", ["int32", "int64"])

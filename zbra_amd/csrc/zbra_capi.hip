@@ -356,7 +356,10 @@ static int encode_batch_dev(DeviceCtx *ctx, const EncodeItem *items, size_t nd, 
     const size_t off_ctr = off_hist + (size_t)n_list * BINS * sizeof(uint32_t);
     const size_t off_lvl = off_ctr + (size_t)n_list * sizeof(BracketCounters);
     const size_t off_pend = off_lvl + (size_t)n_big * SEL_LEVELS * BINS * sizeof(uint32_t);
-    const size_t total = off_pend + ((size_t)n_big + 1) * sizeof(uint32_t);
+    const size_t off_map = align_up(off_pend + ((size_t)n_big + 1) * sizeof(uint32_t), 64);  // tile -> array, written by the set-up kernel
+    uint64_t all_tiles = 0;
+    for (size_t i = 0; i < nd; i++) all_tiles += tiles_of(items[i].n);
+    const size_t total = off_map + (nd > 1 ? (size_t)all_tiles * sizeof(uint32_t) : 0);
     // candidate lists and gathered keys live in the stream's scratch buffer: this call's kernels
     // follow the previous call's in stream order, and the lock keeps another thread's enqueues on
     // the same stream from interleaving with them
@@ -406,21 +409,27 @@ static int encode_batch_dev(DeviceCtx *ctx, const EncodeItem *items, size_t nd, 
     uint32_t *d_pend = (uint32_t *)((char *)s->dev + off_pend);
     const uint64_t *d_ts = (const uint64_t *)((char *)s->dev + off_ts);
     int st = hip_status(hipMemcpyAsync(s->dev, s->host, host_bytes, hipMemcpyHostToDevice, stream));
-    if (st == ZBRA_OK) st = hip_status(hipMemsetAsync((char *)s->dev + off_hist, 0, total - off_hist, stream));
+    if (st == ZBRA_OK) st = hip_status(hipMemsetAsync((char *)s->dev + off_hist, 0, off_map - off_hist, stream));
+    uint32_t *d_map = nd > 1 ? (uint32_t *)((char *)s->dev + off_map) : nullptr;
     if (st == ZBRA_OK) {
-        // Resident workgroups of the run-based passes.  Measured on the encode of one 2^28-row
-        // column: 512 -> 0.877 ms, 768 -> 0.828, 1024 -> 0.838, 2048 -> 0.877, 4096 -> 0.895; batches
-        // of a thousand arrays prefer 2048 (config 3: 5.41 ms against 5.69 at 1024).
-        const unsigned gs = grid_for(ntiles, nd == 1 ? STREAM_GRID_CAP / 2 : STREAM_GRID_CAP);
+        // Workgroups of the bracket pass, each with one contiguous run of tiles.  One 2^28-row
+        // column: 512 -> 0.877 ms for the encode, 768 -> 0.828, 1024 -> 0.838, 2048 -> 0.877,
+        // 4096 -> 0.895.  Batches of a thousand arrays want shorter runs (better balance, at the
+        // price of more end-of-run merges): the pass over a thousand 2^20-row arrays takes 1807 us
+        // with 1024 workgroups, 1754 with 2048, 1649 with 4096, 1643 with 8192, 1688 with 16384,
+        // 2122 with 65536.
+        static const unsigned bracket_grid = [] { const char *e = getenv("ZBRA_HIP_BRACKET_GRID"); return e ? (unsigned)atol(e) : 0u; }();
+        const unsigned gs = grid_for(ntiles, bracket_grid ? bracket_grid : nd == 1 ? STREAM_GRID_CAP / 2 : STREAM_GRID_CAP * 4);
         const unsigned ga = (unsigned)((nd + 255) / 256);
         // workgroups of a many-workgroup select level, dealt to the arrays it finds pending
         static const unsigned level_grid = [] { const char *e = getenv("ZBRA_HIP_LEVEL_GRID"); return e ? (unsigned)atol(e) : 0u; }();
         static const unsigned sparse_tiles = [] { const char *e = getenv("ZBRA_HIP_SPARSE_TILES"); return e ? (unsigned)atol(e) : 0u; }();
-        // 512 workgroups per array that may be pending, up to 2048: a single 2^27-row column with a
+        // 512 workgroups per array that may be pending, up to 4096: a single 2^27-row column with a
         // wide bracket encodes in 0.569 ms with 512, 0.582 with 1024 or 256, 0.596 with 4096 (most of
-        // a large grid only passes through, behind the workgroups that work); a thousand arrays
-        // take 1024, 2048, 4096 or 8192 alike within 3 % (scripts/sweep_level_grid_batches.sh)
-        const unsigned gh = level_grid ? level_grid : n_big >= 4 ? 2048u : 512u * n_big;
+        // a large grid only passes through, behind the workgroups that work); the first level of
+        // a thousand arrays of 2^20 rows takes 718 us with 1024 workgroups, 242 with 2048, 136 with
+        // 4096, 161 with 8192, 222 with 16384 (scripts/sweep_level_grid_batches.sh)
+        const unsigned gh = level_grid ? level_grid : n_big >= 8 ? 4096u : 512u * n_big;
         if (ntiles) {
             hipLaunchKernelGGL(enc_sample_kernel, dim3((unsigned)nd), dim3(SAMPLE_THREADS), 0, stream, d_jobs, (uint32_t)nd,
                                bracket ? 1u : 0u);
@@ -429,7 +438,8 @@ static int encode_batch_dev(DeviceCtx *ctx, const EncodeItem *items, size_t nd, 
             if (n_list)
                 hipLaunchKernelGGL(enc_bracket_kernel, dim3(gs), dim3(THREADS), 0, stream, d_jobs, d_ts, (uint32_t)nd, ntiles);
         }
-        hipLaunchKernelGGL(enc_setup_kernel, dim3((unsigned)nd), dim3(THREADS), 0, stream, d_jobs, (uint32_t)nd, d_pend, small_max);
+        hipLaunchKernelGGL(enc_setup_kernel, dim3((unsigned)nd), dim3(THREADS), 0, stream, d_jobs, (uint32_t)nd, d_pend, small_max,
+                           d_ts, d_map);
         if (ntiles) {
             // the levels are only launched when an array could be too long for one finishing
             // workgroup (its length says so), and end at their first load when none was
@@ -457,7 +467,7 @@ static int encode_batch_dev(DeviceCtx *ctx, const EncodeItem *items, size_t nd, 
                 // the 2^28-row column: 0.92 -> 0.89 ms; the same order for the run-based bracket
                 // pass changed nothing)
                 const unsigned gp = grid_for(ntiles, pack_grid_cap());
-                hipLaunchKernelGGL(enc_pack_kernel, dim3(gp), dim3(THREADS), 0, stream, d_jobs, d_ts, (uint32_t)nd, ntiles,
+                hipLaunchKernelGGL(enc_pack_kernel, dim3(gp), dim3(THREADS), 0, stream, d_jobs, d_ts, d_map, (uint32_t)nd, ntiles,
                                    ((uint64_t)gp == ntiles && ntiles >= 64) ? 1u : 0u);
             }
         } else {

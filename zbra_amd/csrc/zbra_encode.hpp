@@ -839,9 +839,14 @@ __device__ __forceinline__ void finish_run(EncodeJob &job, const EncodeJob::SelS
 // about 11 GB/s, so a long source is better spread over many.  Everything else is left to the one
 // workgroup per array of enc_finish_select_kernel.
 __global__ __launch_bounds__(THREADS) void enc_setup_kernel(EncodeJob *__restrict__ jobs, uint32_t nd,
-                                                             uint32_t *__restrict__ pending, uint64_t small_max) {
+                                                             uint32_t *__restrict__ pending, uint64_t small_max,
+                                                             const uint64_t *__restrict__ tile_start, uint32_t *__restrict__ tile_map) {
     const uint32_t a = blockIdx.x;
     if (a >= nd) return;
+    // tile -> array table of the pack pass (one workgroup per tile there: a binary search over
+    // tile_start would be a dozen dependent loads in front of every tile)
+    if (tile_map)
+        for (uint64_t t = tile_start[a] + threadIdx.x; t < tile_start[a + 1]; t += THREADS) tile_map[t] = a;
     EncodeJob &j = jobs[a];
     __shared__ EncodeJob::SelState s0;
     __shared__ uint64_t src_n;
@@ -970,7 +975,7 @@ __device__ __forceinline__ void level_one(EncodeJob *__restrict__ jobs, uint32_t
     // A digit counted among keys that share earlier digits, and a gather, touch few counters:
     // nothing to merge, so every workgroup is worth having.
     const bool sparse = s0.action == ACT_HIST || s0.lv > 0;
-    if (sparse) tiles_per_wg = sparse_tiles ? sparse_tiles : tiles_per_wg == 0 ? 8u : 16u;  // few arrays / many (measured: 2 to 32 tiles)
+    if (sparse) tiles_per_wg = sparse_tiles ? sparse_tiles : tiles_per_wg == 0 ? 8u : 2u;  // few arrays / many (measured: 1 to 32 tiles; many arrays do not care)
     else if (tiles_per_wg == 0) tiles_per_wg = work_tiles >= 4096 ? 16u : work_tiles < 512 ? 2u : (uint32_t)(work_tiles / 256);
     const uint64_t want = work_tiles / tiles_per_wg;
     const uint32_t eff = want < 1 ? 1u : want < per_array ? (uint32_t)want : per_array;
@@ -1084,7 +1089,10 @@ __device__ __forceinline__ void level_one(EncodeJob *__restrict__ jobs, uint32_t
             }
 #pragma unroll
             for (int q = 0; q < LEVEL_AHEAD; q++)
-                if (q < m) load_tile_from(job.cand, ZBRA_ELEM_I64, t0[q], end[q], 0, x[q]);
+                // every tile slot lies wholly inside its segment's memory (seg_cap is a multiple of
+                // TILE): load it whole, with 16-byte loads, and leave out what is past the fill when
+                // looking at the values, instead of the guarded element loads of a ragged tile
+                if (q < m) load_tile_from(job.cand, ZBRA_ELEM_I64, t0[q], t0[q] + TILE, 0, x[q]);
 #pragma unroll
             for (int q = 0; q < LEVEL_AHEAD; q++) {
                 if (q < m) {
@@ -1136,6 +1144,9 @@ __device__ __forceinline__ void level_one(EncodeJob *__restrict__ jobs, uint32_t
 // `per_array` taking tiles w, w + per_array, ..., so that an array is never left to the two or
 // three workgroups that happen to own its stretch of the submission.  With nothing pending the
 // launch ends at its first load.
+// 221 VGPRs, two waves per SIMD.  Capped at 168 or 128 VGPRs it spills, and a kernel with scratch
+// memory pays for its set-up in every launch, also the ones that find nothing to do (9 -> 18-38 us):
+// the first level of a thousand-array batch got 20 % faster, the encode as a whole did not.
 __global__ __launch_bounds__(THREADS) void enc_level_kernel(EncodeJob *__restrict__ jobs, const uint32_t *__restrict__ pending, uint32_t L,
                                                              uint32_t sparse_tiles) {
     const uint32_t n_list = pending[0];
@@ -1197,7 +1208,7 @@ __device__ __forceinline__ void for_each_select_key(const EncodeJob &job, uint32
             for (uint64_t v0 = 0; v0 < longest; v0 += TILE) {
 #pragma unroll
                 for (int u = 0; u < SEL_AHEAD; u++)
-                    if (v0 < end[u]) load_tile_from(job.cand + (size_t)(g + u) * job.seg_cap, ZBRA_ELEM_I64, v0, end[u], 0, x[u]);
+                    if (v0 < end[u]) load_tile_from(job.cand + (size_t)(g + u) * job.seg_cap, ZBRA_ELEM_I64, v0, v0 + TILE, 0, x[u]);  // whole slot, masked below
 #pragma unroll
                 for (int u = 0; u < SEL_AHEAD; u++) {
                     if (v0 < end[u]) {
@@ -1625,14 +1636,15 @@ __global__ void enc_report_median_kernel(const EncodeJob *__restrict__ jobs, uin
 }
 
 __global__ __launch_bounds__(THREADS) void enc_pack_kernel(const EncodeJob *__restrict__ jobs,
-                                                            const uint64_t *__restrict__ tile_start, uint32_t nd,
+                                                            const uint64_t *__restrict__ tile_start,
+                                                            const uint32_t *__restrict__ tile_map, uint32_t nd,
                                                             uint64_t ntiles, uint32_t xcd_chunked) {
     __shared__ __attribute__((aligned(16))) uint64_t zz64[TILE];  // 64-bit zig-zag values of a raw tile; the packed paths use half of it
     uint32_t *zz = (uint32_t *)zz64;
     // xcd_chunked implies gridDim.x == ntiles: exactly one trip through the loop
     uint64_t t = xcd_chunked ? xcd_chunked_tile(blockIdx.x, ntiles) : blockIdx.x;
     for (; t < ntiles; t += gridDim.x) {
-        const uint32_t a = nd > 1 ? find_array(tile_start, nd, t) : 0;
+        const uint32_t a = nd > 1 ? tile_map[t] : 0;
         const EncodeJob &job = jobs[a];
         if (job.width == WIDTH_SKIP) continue;
         const uint64_t v0 = (t - tile_start[a]) * TILE;
