@@ -349,15 +349,15 @@ struct BinaryFile {
         }
         if (w.unsupported_blob)
             return BinaryError{BinaryError::CompressionError, "byte blobs are written with CompressionAlgorithm::None only", ZBRA_ERR_INVALID_ARG};
-        std::vector<uint8_t> frames;
-        auto offs = write_int_arrays_compressed(frames, w.arrays);
-        if (offs.is_err()) return offs.error();
+        auto staged = encode_frames_staged(w.arrays);
+        if (staged.is_err()) return staged.error();
+        const StagedFrames &fr = staged.value();
         std::vector<uint8_t> image;
-        image.reserve(w.out.size() + frames.size());
+        image.reserve(w.out.size() + fr.offsets.back());
         size_t prev = 0;
         for (size_t i = 0; i < w.arrays.size(); i++) {
             image.insert(image.end(), w.out.begin() + prev, w.out.begin() + w.cuts[i]);
-            image.insert(image.end(), frames.begin() + offs.value()[i], frames.begin() + offs.value()[i + 1]);
+            image.insert(image.end(), fr.buf.get() + fr.offsets[i], fr.buf.get() + fr.offsets[i + 1]);
             prev = w.cuts[i];
         }
         image.insert(image.end(), w.out.begin() + prev, w.out.end());

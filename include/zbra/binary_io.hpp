@@ -3,8 +3,11 @@
 // over a byte vector (Write) and a cursor (Read).  The u32 variant narrows / widens on the device
 // (no intermediate Vec<i64> as in binary.rs:666-674); the usize variant is the i64 path.
 #pragma once
+#include <algorithm>
 #include <cstring>
+#include <memory>
 #include <string>
+#include <thread>
 
 #include "compression.hpp"
 
@@ -110,7 +113,14 @@ struct IntArrayRef {
 // write_int_array_compressed / write_u32_array_compressed (binary.rs:639-645, 666-669) for every
 // array of `arrays` in ONE submission: their frames are appended to `w` back to back;
 // frame i = w[offsets[i] .. offsets[i+1]) relative to w's size at the call.
-inline Result<std::vector<size_t>> write_int_arrays_compressed(std::vector<uint8_t> &w, const std::vector<IntArrayRef> &arrays) {
+// The frames land in an UNINITIALISED staging buffer of the worst-case size (13 + 8 n bytes per
+// array: value-initialising it, as a std::vector would, touches several times the bytes that are
+// ever written) and are returned with their offsets: frame i = buf[offsets[i] .. offsets[i+1]).
+struct StagedFrames {
+    std::unique_ptr<uint8_t[]> buf;
+    std::vector<uint64_t> offsets;  // arrays.size() + 1
+};
+inline Result<StagedFrames> encode_frames_staged(const std::vector<IntArrayRef> &arrays) {
     std::vector<zbra_encode_desc> descs(arrays.size());
     size_t bound = 0;
     for (size_t i = 0; i < arrays.size(); i++) {
@@ -118,13 +128,19 @@ inline Result<std::vector<size_t>> write_int_arrays_compressed(std::vector<uint8
                                     (uint32_t)(arrays[i].is_u32 ? ZBRA_ELEM_U32 : ZBRA_ELEM_I64), 0};
         bound += 8 + zbra_hip_encode_bound(arrays[i].n);
     }
-    const size_t at = w.size();
-    w.resize(at + bound);
-    std::vector<uint64_t> offs(arrays.size() + 1);
-    const int st = zbra_hip_encode_frames(descs.data(), descs.size(), w.data() + at, bound, offs.data(), nullptr);
-    if (st != ZBRA_OK) { w.resize(at); return detail::make_error(st, BinaryError::CompressionError); }
-    w.resize(at + offs.back());
-    return std::vector<size_t>(offs.begin(), offs.end());
+    StagedFrames f;
+    f.buf.reset(new uint8_t[bound ? bound : 1]);
+    f.offsets.assign(arrays.size() + 1, 0);
+    const int st = zbra_hip_encode_frames(descs.data(), descs.size(), f.buf.get(), bound, f.offsets.data(), nullptr);
+    if (st != ZBRA_OK) return detail::make_error(st, BinaryError::CompressionError);
+    return f;
+}
+inline Result<std::vector<size_t>> write_int_arrays_compressed(std::vector<uint8_t> &w, const std::vector<IntArrayRef> &arrays) {
+    auto staged = encode_frames_staged(arrays);
+    if (staged.is_err()) return staged.error();
+    const StagedFrames &f = staged.value();
+    w.insert(w.end(), f.buf.get(), f.buf.get() + f.offsets.back());
+    return std::vector<size_t>(f.offsets.begin(), f.offsets.end());
 }
 
 // Every int array of a .zbra image, found without decoding (zbra_hip_file_index) and then decoded
@@ -158,9 +174,23 @@ inline Result<DecodedFile> read_file_int_arrays(const uint8_t *image, size_t len
         size_t n = 0;
         st = zbra_hip_decoded_count(image + idx[i].offset, idx[i].len, idx[i].count, &n);
         if (st != ZBRA_OK) return detail::make_error(st, BinaryError::DecompressionError);
-        if (idx[i].kind == ZBRA_ELEM_U32) { f.arrays[i].u32.resize(n); outs[i] = f.arrays[i].u32.data(); }
-        else { f.arrays[i].i64.resize(n); outs[i] = f.arrays[i].i64.data(); }
         idx[i].count = n;  // what is asked of the decode: an array that yields nothing has no output buffer
+    }
+    // A std::vector comes value-initialised: gigabytes of zeros written (and pages faulted in) by
+    // one thread took ten times as long as the decode itself.  Several threads share the arrays.
+    {
+        const unsigned hw = std::thread::hardware_concurrency();
+        const size_t nthreads = idx.size() < 2 ? 1 : std::min<size_t>(std::min<size_t>(8, hw ? hw / 2 + 1 : 2), idx.size());
+        auto allocate = [&](size_t first) {
+            for (size_t i = first; i < idx.size(); i += nthreads) {
+                if (idx[i].kind == ZBRA_ELEM_U32) { f.arrays[i].u32.resize(idx[i].count); outs[i] = f.arrays[i].u32.data(); }
+                else { f.arrays[i].i64.resize(idx[i].count); outs[i] = f.arrays[i].i64.data(); }
+            }
+        };
+        std::vector<std::thread> pool;
+        for (size_t t = 1; t < nthreads; t++) pool.emplace_back(allocate, t);
+        allocate(0);
+        for (std::thread &t : pool) t.join();
     }
     st = zbra_hip_file_decode(image, len, idx.data(), idx.size(), outs.data(), nullptr);
     if (st != ZBRA_OK) return detail::make_error(st, BinaryError::DecompressionError);
