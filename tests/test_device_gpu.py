@@ -311,6 +311,28 @@ def test_dev_encodes_from_threads_on_one_stream(env):
         assert encs[i][:len(want[i])].cpu().numpy().tobytes() == want[i], i
 
 
+def test_dev_encodes_on_more_streams_than_keep_scratch(env):
+    """Only 16 streams keep a scratch buffer; a seventeenth takes over the least recently used one
+    after a device synchronisation.  Twenty streams, twice round, every output exact."""
+    torch, device, oc, L = env
+    n = 200_003
+    col = column("w31", n, 123)
+    want = oc.compress_int_array(col)
+    v = torch.from_numpy(col).cuda()
+    streams = [torch.cuda.Stream() for _ in range(20)]
+    encs = [torch.zeros(device.encode_bound(n), dtype=torch.uint8, device="cuda") for _ in streams]
+    ress = [device.new_results(1, "cuda") for _ in streams]
+    torch.cuda.synchronize()
+    for _ in range(2):
+        for st, enc, res in zip(streams, encs, ress):
+            device.encode_dev(v, enc, res, stream=st)
+    torch.cuda.synchronize()
+    for enc, res in zip(encs, ress):
+        r = device.read_results(res)[0]
+        assert r.status == 0 and r.out_count == len(want)
+        assert enc[:len(want)].cpu().numpy().tobytes() == want
+
+
 @pytest.mark.parametrize("dtype_name", ["int32", "int64"])
 def test_more_than_2_31_values(env, dtype_name):
     """One array of 2^31 + 5 values: every value index, bit offset and count beyond 32 bits
