@@ -172,12 +172,19 @@ __global__ __launch_bounds__(ENUM_THREADS) void enum_counts_few_kernel(const uin
             u32x4 x[ENUM_TILE / 256];
 #pragma unroll
             for (int st = 0; st < ENUM_TILE / 256; st++) x[st] = __builtin_nontemporal_load(src + st * 64);
+            // variant by variant over the lane's 32 tags: a compare and an add-with-carry per tag
+            // and live variant (all tags against all variants with byte-packed counters took
+            // three times the vector instructions and bound the kernel: 222 us for 2^28 rows)
 #pragma unroll
-            for (int st = 0; st < ENUM_TILE / 256; st++) {
-                enum_count_tag(x[st].x, vt, live, lo, hi);
-                enum_count_tag(x[st].y, vt, live, lo, hi);
-                enum_count_tag(x[st].z, vt, live, lo, hi);
-                enum_count_tag(x[st].w, vt, live, lo, hi);
+            for (int b = 0; b < ENUM_FEW; b++) {
+                if ((live >> b) & 1u) {  // uniform
+                    uint32_t c = 0;
+#pragma unroll
+                    for (int st = 0; st < ENUM_TILE / 256; st++)
+                        c += (uint32_t)(x[st].x == vt[b]) + (uint32_t)(x[st].y == vt[b]) + (uint32_t)(x[st].z == vt[b]) + (uint32_t)(x[st].w == vt[b]);
+                    if (b < 4) lo += c << (8 * b);  // at most 32 per byte
+                    else hi += c << (8 * (b - 4));
+                }
             }
         } else {
             for (uint32_t st = 0; st < (uint32_t)ENUM_TILE / 64; st++) {
