@@ -94,7 +94,7 @@ def main():
     ap.add_argument("--scale-log2", type=int, default=0, help="divide the row counts by 2^this (smoke runs)")
     ap.add_argument("--reps", type=int, default=10)
     ap.add_argument("--encode-only", action="store_true", help="no median check, no decode (kernel traces)")
-    ap.add_argument("--only", choices=["a", "b"], help="config 4: only the clustered (a) or only the time-series (b) Int columns")
+    ap.add_argument("--only", choices=["a", "b", "tags"], help="config 4: only the clustered (a) or the time-series (b) Int columns, or only the tag columns")
     args = ap.parse_args()
     global ENCODE_ONLY
     ENCODE_ONLY = args.encode_only
@@ -127,6 +127,8 @@ def main():
             for _, a, bcol in variants:
                 ints += [a, bcol] if not args.only else [a] if args.only == "a" else [bcol]
         print(json.dumps(run_batch(tags, "config 4 (one GPU's 2^29 rows): enum tags -> u32, %d Blocks" % blocks, args.reps)), flush=True)
+        if args.only == "tags":
+            return
         print(json.dumps(run_batch(ints, "config 4: Int columns of the variants, %d arrays" % len(ints), args.reps)), flush=True)
         if args.only:
             return
