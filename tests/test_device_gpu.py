@@ -197,7 +197,7 @@ def test_full_size_roundtrip_properties(env):
 def test_decode_garbage_never_reads_or_writes_outside(env):
     """Random and adversarial header bytes: whatever the 13 header bytes claim, the decoder only
     reads inside [data, data + len) and writes inside out[0:count].  Every case is checked against
-    the oracle's verdict (status, and values when it accepts)."""
+    the oracle's answer (status, and values when it accepts)."""
     torch, device, oc, L = env
     rng = np.random.default_rng(4242)
     guard = 64

@@ -172,7 +172,7 @@ struct HostPipe {
     // the workers write it, and 4-KiB faults then cost more than the transfer.  Asking for
     // transparent huge pages on the whole 2-MiB blocks inside it cuts the faults by 512x where
     // the system allows it (THP "madvise" or "always"); elsewhere the call does nothing.  It is
-    // advice about paging only.  ZBRA_HIP_HOST_HUGEPAGES=0 leaves the caller's memory alone.
+    // a paging hint only.  ZBRA_HIP_HOST_HUGEPAGES=0 leaves the caller's memory alone.
     static void advise_huge(void *host, size_t bytes) {
         static const bool on = [] {
             const char *e = std::getenv("ZBRA_HIP_HOST_HUGEPAGES");
