@@ -479,12 +479,16 @@ static int encode_batch_dev(DeviceCtx *ctx, const EncodeItem *items, size_t nd, 
                                    frames->cap, frames->offsets);
             hipLaunchKernelGGL(enc_finalize_kernel, dim3(ga), dim3(256), 0, stream, d_jobs, (uint32_t)nd, d_results);
             if (ntiles) {
-                // one workgroup per tile, each XCD on one contiguous eighth of the tiles (encode of
-                // the 2^28-row column: 0.92 -> 0.89 ms; the same order for the run-based bracket
-                // pass changed nothing)
+                // One workgroup per tile.  Batches deal each XCD one contiguous eighth of the tiles
+                // (a thousand 2^20-row arrays: 3.98 against 4.11 ms for the encode, the 1024 ragged
+                // columns 4.70 against 5.03); a single array takes the plain order, which is as fast
+                // at 2^28 rows and 1-4 % faster at 2^27 (pack at width 12: 213 against 221 us,
+                // raw: 350 against 364).  ZBRA_HIP_PACK_XCD=0|1 forces one or the other.
                 const unsigned gp = grid_for(ntiles, pack_grid_cap());
+                static const int pack_xcd_env = [] { const char *e = getenv("ZBRA_HIP_PACK_XCD"); return e ? atoi(e) : -1; }();
+                const bool pack_xcd = pack_xcd_env >= 0 ? pack_xcd_env != 0 : nd > 1;
                 hipLaunchKernelGGL(enc_pack_kernel, dim3(gp), dim3(THREADS), 0, stream, d_jobs, d_ts, d_map, (uint32_t)nd, ntiles,
-                                   ((uint64_t)gp == ntiles && ntiles >= 64) ? 1u : 0u);
+                                   (pack_xcd && (uint64_t)gp == ntiles && ntiles >= 64) ? 1u : 0u);
             }
         } else {
             hipLaunchKernelGGL(enc_report_median_kernel, dim3(ga), dim3(256), 0, stream, d_jobs, (uint32_t)nd, d_results);
