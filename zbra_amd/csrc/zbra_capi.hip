@@ -146,13 +146,20 @@ static inline uint64_t decode_tiles_of(uint64_t count, uint32_t kind) {
     return (count + t - 1) / t;
 }
 // The tile order of a decode launch.  Dealing each XCD one contiguous eighth of the tiles keeps the
-// packed bytes that neighbouring tiles share in one L2: worth 1.5-5 % from about 10 bits per value
-// up (2^27 rows: 0.2118 against 0.2162 ms at width 11, 0.2488 against 0.2609 at width 25).  Narrow
-// values have few packed bytes to share and lose 4-6 % to it (width 2: 0.2149 against 0.2040 ms,
-// width 6: 0.2154 against 0.2046, u32 tags of width 4: 0.2122 against 0.2040): they take the plain
-// order.  The host decides from what it knows without reading the device's bytes: the encoded
-// bytes and the value count of the submission.
-static inline bool wants_xcd_order(uint64_t encoded_bytes, uint64_t values) { return encoded_bytes * 8 >= values * 10; }
+// packed bytes that neighbouring tiles share in one L2.  Interleaved A/B, 2^27 rows, chunked
+// against plain order: widths 2-9 lose 1.5-7 % to it (0.2168 against 0.2058 ms at width 2, 0.2198
+// against 0.2044 at width 7), widths 11-31 gain up to 5 % (0.2494 against 0.2626 ms at width 25),
+// and the raw fallback loses again (0.3805 against 0.3673 ms at width 32, 0.4102 against 0.3673 on
+// a full-range column).  Batches of hundreds of packed arrays want it also when they are narrow
+// (1024 ragged columns: 1.96 against 2.18 ms; 128 tag columns: 0.427 against 0.434).  So: chunked
+// below 32 encoded bits per value (not mostly raw) for a batch, and from 10 to 31 bits for a single
+// array; the host knows the bits per value from the frames' lengths and counts without reading a
+// byte on the device.
+static inline bool wants_xcd_order(uint64_t encoded_bytes, uint64_t values, size_t nd) {
+    const uint64_t bits = encoded_bytes * 8;
+    if (bits >= values * 32) return false;
+    return nd > 1 || bits >= values * 10;
+}
 
 static void launch_decode(hipStream_t stream, const DecodePlan *plans, const uint64_t *ts, const uint32_t *tmap, uint32_t nd,
                           uint64_t ntiles, bool wide) {
@@ -210,7 +217,7 @@ static int decode_batch_dev(DeviceCtx *ctx, const zbra_array_desc *descs, size_t
         uint64_t *tile_start = (uint64_t *)((char *)s->dev + 64);
         hipLaunchKernelGGL(plan_decode_one_kernel, dim3(1), dim3(64), 0, stream, descs[0], ntiles, plan, tile_start,
                            d_results);
-        if (ntiles) launch_decode(stream, plan, tile_start, nullptr, 1u, ntiles, wants_xcd_order(descs[0].len, descs[0].count));
+        if (ntiles) launch_decode(stream, plan, tile_start, nullptr, 1u, ntiles, wants_xcd_order(descs[0].len, descs[0].count, 1));
         int st = hip_status(hipGetLastError());
         int st2 = ctx->release(s, stream);
         return st != ZBRA_OK ? st : st2;
@@ -240,7 +247,7 @@ static int decode_batch_dev(DeviceCtx *ctx, const zbra_array_desc *descs, size_t
         uint32_t *d_map = (uint32_t *)((char *)s->dev + off_map);
         hipLaunchKernelGGL(plan_decode_batch_kernel, dim3((unsigned)nd), dim3(256), 0, stream, d_descs, (uint32_t)nd, d_ts,
                            d_plans, d_map, d_results);
-        if (ntiles) launch_decode(stream, d_plans, d_ts, d_map, (uint32_t)nd, ntiles, wants_xcd_order(all_bytes, all_values));
+        if (ntiles) launch_decode(stream, d_plans, d_ts, d_map, (uint32_t)nd, ntiles, wants_xcd_order(all_bytes, all_values, nd));
         st = hip_status(hipGetLastError());
     }
     int st2 = ctx->release(s, stream);
@@ -307,7 +314,7 @@ static int decode_batch_dev_noalloc(DeviceCtx *ctx, const zbra_array_desc *descs
         hipLaunchKernelGGL(plan_decode_noalloc_kernel, dim3(n), dim3(256), 0, stream, c, (uint32_t)first, n, sc->plans, sc->tile_start,
                            sc->tile_map, d_results);
     }
-    if (ntiles) launch_decode(stream, sc->plans, sc->tile_start, sc->tile_map, (uint32_t)nd, ntiles, wants_xcd_order(all_bytes, all_values));
+    if (ntiles) launch_decode(stream, sc->plans, sc->tile_start, sc->tile_map, (uint32_t)nd, ntiles, wants_xcd_order(all_bytes, all_values, nd));
     return hip_status(hipGetLastError());
 }
 
@@ -574,7 +581,7 @@ static int decode_host_pieces(DeviceCtx *ctx, const uint8_t *data, size_t used, 
         if (b1 > b0) ZBRA_TRY(ctx->pipe_up.to_device((char *)ctx->dev_in.ptr + b0, data + b0, b1 - b0, up));
         const uint64_t v0 = (uint64_t)c * per, nv = count - v0 < per ? count - v0 : per;
         launch_decode(up, (const DecodePlan *)((char *)s->dev + c * 128), (const uint64_t *)((char *)s->dev + c * 128 + 64), nullptr, 1u,
-                      decode_tiles_of(nv, kind), w >= 10);
+                      decode_tiles_of(nv, kind), w >= 10 && w < 32);
         ZBRA_HIP_TRY(hipGetLastError());
         ZBRA_HIP_TRY(hipEventRecord(ctx->piece_done[c % 4], up));
         submitted++;
@@ -945,7 +952,7 @@ int zbra_hip_bp64_unpack(const uint8_t *packed, size_t packed_len, size_t count,
     uint64_t *tile_start = (uint64_t *)((char *)ctx->dev_tmp.ptr + 64);
     hipLaunchKernelGGL(plan_unpack_kernel, dim3(1), dim3(64), 0, ctx->stream, (const uint8_t *)ctx->dev_in.ptr,
                        (uint64_t)packed_len, (uint64_t)count, ctx->dev_out.ptr, ntiles, plan, tile_start);
-    launch_decode(ctx->stream, plan, tile_start, nullptr, 1u, ntiles, w >= 10);
+    launch_decode(ctx->stream, plan, tile_start, nullptr, 1u, ntiles, w >= 10 && w < 32);
     ZBRA_HIP_TRY(hipGetLastError());
     ZBRA_TRY(ctx->pipe.to_host(out, ctx->dev_out.ptr, count * 8, ctx->stream));
     *out_count = count;
