@@ -78,16 +78,17 @@ struct DecodeConfig {
     int threads = 512;
     int nt = 3;  // bit 0: nontemporal loads, bit 1: nontemporal stores
     int direct = 0;
-    int xcd = 2;  // XCD-chunked tile order: 0 never, 1 always, 2 by the submission's bits per value (see wants_xcd_order)
+    int xcd = 2;  // tile order: 2 = by the submission's bits per value (decode_tile_order); 0, 1 or a group size force one
     unsigned grid_cap = 0x7FFFFFFFu;  // one workgroup per tile
 };
 
 template <int DT, int TH>
 static void launch_decode_t(const DecodeConfig &c, unsigned grid, hipStream_t stream, const DecodePlan *plans,
-                            const uint64_t *ts, const uint32_t *tmap, uint32_t nd, uint64_t ntiles, bool wide) {
+                            const uint64_t *ts, const uint32_t *tmap, uint32_t nd, uint64_t ntiles, uint32_t order) {
     const dim3 g(grid), b(TH);
-    const bool chunk = c.xcd == 1 || (c.xcd == 2 && wide);
-    const uint32_t x = (chunk && (uint64_t)grid == ntiles && ntiles >= 64) ? 1u : 0u;
+    // c.xcd: 2 = the order the caller worked out (decode_tile_order); anything else forces that order (tuning)
+    const uint32_t want = c.xcd == 2 ? order : (uint32_t)c.xcd;
+    const uint32_t x = ((uint64_t)grid == ntiles && ntiles >= 64) ? want : 0u;
 #define ZBRA_LAUNCH_DECODE(NTV, DIR) \
     hipLaunchKernelGGL((decode_tiles_kernel<DT, TH, NTV, DIR>), g, b, 0, stream, plans, ts, tmap, nd, ntiles, x)
     switch ((c.nt & 3) * 2 + (c.direct ? 1 : 0)) {
@@ -104,7 +105,7 @@ static void launch_decode_t(const DecodeConfig &c, unsigned grid, hipStream_t st
 }
 
 typedef void (*DecodeLauncher)(const DecodeConfig &, unsigned, hipStream_t, const DecodePlan *, const uint64_t *,
-                               const uint32_t *, uint32_t, uint64_t, bool);
+                               const uint32_t *, uint32_t, uint64_t, uint32_t);
 struct DecodeShape { int tile, threads; DecodeLauncher fn; };
 static const DecodeShape kDecodeShapes[] = {  // the default and the alternatives it was measured against
     {2048, 512, launch_decode_t<2048, 512>}, {2048, 256, launch_decode_t<2048, 256>}, {1024, 256, launch_decode_t<1024, 256>},
@@ -130,7 +131,7 @@ static const DecodeConfig &decode_config() {
             int t = 0, th = 0, n = 0, d = 0;
             if (sscanf(e, "%d:%d:%d:%d", &t, &th, &n, &d) == 4) apply_variant(c, t, th, n, d);
         }
-        if (const char *e = getenv("ZBRA_HIP_DECODE_XCD")) c.xcd = atoi(e);  // 0 never, 1 always, 2 by width
+        if (const char *e = getenv("ZBRA_HIP_DECODE_XCD")) c.xcd = atoi(e);  // 0 plain, 1 chunked, 2 by bits per value, >= 4 groups of that many tiles
         if (const char *e = getenv("ZBRA_HIP_DECODE_GRID")) {
             const long v = atol(e);
             if (v > 0) c.grid_cap = (unsigned)v;
@@ -145,26 +146,32 @@ static inline uint64_t decode_tiles_of(uint64_t count, uint32_t kind) {
     const uint64_t t = (uint64_t)decode_config().tile * (kind == ZBRA_ELEM_U32 ? 2 : 1);
     return (count + t - 1) / t;
 }
-// The tile order of a decode launch.  Dealing each XCD one contiguous eighth of the tiles keeps the
-// packed bytes that neighbouring tiles share in one L2.  Interleaved A/B, 2^27 rows, chunked
-// against plain order: widths 2-9 lose 1.5-7 % to it (0.2168 against 0.2058 ms at width 2, 0.2198
-// against 0.2044 at width 7), widths 11-31 gain up to 5 % (0.2494 against 0.2626 ms at width 25),
-// and the raw fallback loses again (0.3805 against 0.3673 ms at width 32, 0.4102 against 0.3673 on
-// a full-range column).  Batches of hundreds of packed arrays want it also when they are narrow
-// (1024 ragged columns: 1.96 against 2.18 ms; 128 tag columns: 0.427 against 0.434).  So: chunked
-// below 32 encoded bits per value (not mostly raw) for a batch, and from 10 to 31 bits for a single
-// array; the host knows the bits per value from the frames' lengths and counts without reading a
+// The tile order of a decode launch (the kernel's xcd_chunked argument): 0 = tile b for workgroup b,
+// 1 = each XCD walks one contiguous eighth of the tiles, G >= 4 = inside every run of 8 G tiles
+// each XCD takes G consecutive ones.  Which is fastest depends on how many packed bytes a tile
+// has (interleaved A/B in one process, profiles/r02_ab_decode_tile_order.txt; 2^27 rows unless said):
+//   widths 2-9     plain       0.2058 against 0.2168 ms chunked at width 2; u32 tags 0.2036 / 0.2128
+//   widths 11-13   chunked     0.2122 against 0.2169 plain, 0.2265 grouped (2^28 rows, width 12:
+//                              0.4168 / 0.4336 / 0.4436)
+//   widths 16-31   groups of 16  width 25: 0.2365 against 0.2495 chunked, 0.2618 plain (2^28 rows:
+//                              0.4661 / 0.4860 / 0.5190; 2^25: 0.0660 / 0.0698 / 0.0705)
+//   raw (>= 32)    plain       0.3673 against 0.3805 chunked; groups win at 2^27 rows (0.3505) and
+//                              lose at 2^28 (0.7895 against 0.7381), so they are not used
+// Batches of hundreds of packed arrays are fastest chunked whatever their widths (1024 ragged
+// columns: 1.94 ms against 1.98 in groups of 16 and 2.18 plain).  The host decides from the
+// encoded bits per value, which it knows from the frames' lengths and counts without reading a
 // byte on the device.
-static inline bool wants_xcd_order(uint64_t encoded_bytes, uint64_t values, size_t nd) {
+static inline uint32_t decode_tile_order(uint64_t encoded_bytes, uint64_t values, size_t nd) {
     const uint64_t bits = encoded_bytes * 8;
-    if (bits >= values * 32) return false;
-    return nd > 1 || bits >= values * 10;
+    if (bits >= values * 32) return 0;  // raw, or mostly raw
+    if (nd > 1) return 1;
+    return bits >= values * 16 ? 16u : bits >= values * 10 ? 1u : 0u;
 }
 
 static void launch_decode(hipStream_t stream, const DecodePlan *plans, const uint64_t *ts, const uint32_t *tmap, uint32_t nd,
-                          uint64_t ntiles, bool wide) {
+                          uint64_t ntiles, uint32_t order) {
     const DecodeConfig &c = decode_config();
-    g_decode_fn(c, grid_for(ntiles, c.grid_cap), stream, plans, ts, tmap, nd, ntiles, wide);
+    g_decode_fn(c, grid_for(ntiles, c.grid_cap), stream, plans, ts, tmap, nd, ntiles, order);
 }
 
 constexpr unsigned STREAM_GRID_CAP = 256 * 8;
@@ -217,7 +224,7 @@ static int decode_batch_dev(DeviceCtx *ctx, const zbra_array_desc *descs, size_t
         uint64_t *tile_start = (uint64_t *)((char *)s->dev + 64);
         hipLaunchKernelGGL(plan_decode_one_kernel, dim3(1), dim3(64), 0, stream, descs[0], ntiles, plan, tile_start,
                            d_results);
-        if (ntiles) launch_decode(stream, plan, tile_start, nullptr, 1u, ntiles, wants_xcd_order(descs[0].len, descs[0].count, 1));
+        if (ntiles) launch_decode(stream, plan, tile_start, nullptr, 1u, ntiles, decode_tile_order(descs[0].len, descs[0].count, 1));
         int st = hip_status(hipGetLastError());
         int st2 = ctx->release(s, stream);
         return st != ZBRA_OK ? st : st2;
@@ -247,7 +254,7 @@ static int decode_batch_dev(DeviceCtx *ctx, const zbra_array_desc *descs, size_t
         uint32_t *d_map = (uint32_t *)((char *)s->dev + off_map);
         hipLaunchKernelGGL(plan_decode_batch_kernel, dim3((unsigned)nd), dim3(256), 0, stream, d_descs, (uint32_t)nd, d_ts,
                            d_plans, d_map, d_results);
-        if (ntiles) launch_decode(stream, d_plans, d_ts, d_map, (uint32_t)nd, ntiles, wants_xcd_order(all_bytes, all_values, nd));
+        if (ntiles) launch_decode(stream, d_plans, d_ts, d_map, (uint32_t)nd, ntiles, decode_tile_order(all_bytes, all_values, nd));
         st = hip_status(hipGetLastError());
     }
     int st2 = ctx->release(s, stream);
@@ -314,7 +321,7 @@ static int decode_batch_dev_noalloc(DeviceCtx *ctx, const zbra_array_desc *descs
         hipLaunchKernelGGL(plan_decode_noalloc_kernel, dim3(n), dim3(256), 0, stream, c, (uint32_t)first, n, sc->plans, sc->tile_start,
                            sc->tile_map, d_results);
     }
-    if (ntiles) launch_decode(stream, sc->plans, sc->tile_start, sc->tile_map, (uint32_t)nd, ntiles, wants_xcd_order(all_bytes, all_values, nd));
+    if (ntiles) launch_decode(stream, sc->plans, sc->tile_start, sc->tile_map, (uint32_t)nd, ntiles, decode_tile_order(all_bytes, all_values, nd));
     return hip_status(hipGetLastError());
 }
 
@@ -581,7 +588,7 @@ static int decode_host_pieces(DeviceCtx *ctx, const uint8_t *data, size_t used, 
         if (b1 > b0) ZBRA_TRY(ctx->pipe_up.to_device((char *)ctx->dev_in.ptr + b0, data + b0, b1 - b0, up));
         const uint64_t v0 = (uint64_t)c * per, nv = count - v0 < per ? count - v0 : per;
         launch_decode(up, (const DecodePlan *)((char *)s->dev + c * 128), (const uint64_t *)((char *)s->dev + c * 128 + 64), nullptr, 1u,
-                      decode_tiles_of(nv, kind), w >= 10 && w < 32);
+                      decode_tiles_of(nv, kind), w >= 32 ? 0u : w >= 16 ? 16u : w >= 10 ? 1u : 0u);
         ZBRA_HIP_TRY(hipGetLastError());
         ZBRA_HIP_TRY(hipEventRecord(ctx->piece_done[c % 4], up));
         submitted++;
@@ -952,7 +959,7 @@ int zbra_hip_bp64_unpack(const uint8_t *packed, size_t packed_len, size_t count,
     uint64_t *tile_start = (uint64_t *)((char *)ctx->dev_tmp.ptr + 64);
     hipLaunchKernelGGL(plan_unpack_kernel, dim3(1), dim3(64), 0, ctx->stream, (const uint8_t *)ctx->dev_in.ptr,
                        (uint64_t)packed_len, (uint64_t)count, ctx->dev_out.ptr, ntiles, plan, tile_start);
-    launch_decode(ctx->stream, plan, tile_start, nullptr, 1u, ntiles, w >= 10 && w < 32);
+    launch_decode(ctx->stream, plan, tile_start, nullptr, 1u, ntiles, w >= 32 ? 0u : w >= 16 ? 16u : w >= 10 ? 1u : 0u);
     ZBRA_HIP_TRY(hipGetLastError());
     ZBRA_TRY(ctx->pipe.to_host(out, ctx->dev_out.ptr, count * 8, ctx->stream));
     *out_count = count;

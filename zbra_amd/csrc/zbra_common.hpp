@@ -93,4 +93,14 @@ __device__ __forceinline__ uint64_t xcd_chunked_tile(uint64_t b, uint64_t ntiles
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
 }
 
+// The same idea at a finer grain: inside every run of 8 * G consecutive tiles XCD x takes tiles
+// [x * G, x * G + G), so neighbouring tiles still meet in one L2 while all eight XCDs work in the
+// same few megabytes of memory.  Tiles past the last whole run keep their index.
+__device__ __forceinline__ uint64_t xcd_grouped_tile(uint64_t b, uint64_t ntiles, uint32_t G) {
+    const uint64_t span = 8ull * G;
+    if (b >= ntiles / span * span) return b;
+    const uint64_t within = b % span;
+    return b - within + (within & 7) * G + (within >> 3);
+}
+
 }  // namespace zbra

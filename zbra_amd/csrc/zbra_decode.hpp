@@ -364,7 +364,7 @@ __global__ __launch_bounds__(TH) void decode_tiles_kernel(const DecodePlan *__re
     // u32 outputs are half as wide, so their tiles hold twice the values (same bytes written)
     __shared__ __attribute__((aligned(16))) uint32_t lds[lds_dwords<2 * DT>()];
     // xcd_chunked implies gridDim.x == ntiles: exactly one trip through the loop
-    uint64_t t = xcd_chunked ? xcd_chunked_tile(blockIdx.x, ntiles) : blockIdx.x;
+    uint64_t t = xcd_chunked == 1 ? xcd_chunked_tile(blockIdx.x, ntiles) : xcd_chunked ? xcd_grouped_tile(blockIdx.x, ntiles, xcd_chunked) : blockIdx.x;
     for (; t < ntiles; t += gridDim.x) {
         const uint32_t a = nd > 1 ? tile_map[t] : 0;
         const DecodePlan p = plans[a];
