@@ -252,7 +252,8 @@ int zbra_hip_encode_batch_dev(const zbra_encode_desc *descs, size_t nd, zbra_dev
  * nd + 1 words, frame i = [d_offsets[i], d_offsets[i+1]).  descs[i].out and .cap are ignored.
  * Frames that would pass `cap` are not written and get ZBRA_ERR_CAPACITY in d_results (may be
  * NULL); cap = sum of 8 + zbra_hip_encode_bound(n_i) always suffices.  An empty array is the
- * 8-byte frame count = 0, clen = 0. */
+ * 8-byte frame count = 0, clen = 0.  One call lays out at most 2^20 frames (ZBRA_ERR_INVALID_ARG
+ * beyond; the other batched calls take tables of any length and work through them in pieces). */
 int zbra_hip_encode_frames_dev(const zbra_encode_desc *descs, size_t nd, uint8_t *d_out, size_t cap, uint64_t *d_offsets,
                                zbra_dev_result *d_results, void *stream);
 

@@ -82,30 +82,43 @@ struct DecodeConfig {
     unsigned grid_cap = 0x7FFFFFFFu;  // one workgroup per tile
 };
 
+// Work-items one dispatch may have: the grid of an AQL packet is 32 bits wide in work-items, and
+// a larger launch is not refused but silently runs the low 32 bits' worth of workgroups.  Launches
+// with one workgroup per tile are cut (decode) or capped (pack) by this.
+// zbra_tuning_set_launch_limit lowers it so that tests reach the cut with small inputs.
+static uint64_t g_launch_limit = 0xFFFFFFFFull;
+
 template <int DT, int TH>
-static void launch_decode_t(const DecodeConfig &c, unsigned grid, hipStream_t stream, const DecodePlan *plans,
-                            const uint64_t *ts, const uint32_t *tmap, uint32_t nd, uint64_t ntiles, uint32_t order) {
-    const dim3 g(grid), b(TH);
+static void launch_decode_t(const DecodeConfig &c, hipStream_t stream, const DecodePlan *plans, const uint64_t *ts,
+                            const uint32_t *tmap, uint32_t nd, uint64_t all_tiles, uint32_t order) {
     // c.xcd: 2 = the order the caller worked out (decode_tile_order); anything else forces that order (tuning)
     const uint32_t want = c.xcd == 2 ? order : (uint32_t)c.xcd;
-    const uint32_t x = ((uint64_t)grid == ntiles && ntiles >= 64) ? want : 0u;
+    // tiles per launch: a multiple of 8 (whole rounds of the XCDs) within the dispatch limit
+    uint64_t per = g_launch_limit / TH & ~7ull;
+    if (per == 0) per = 8;
+    for (uint64_t base = 0; base < all_tiles; base += per) {
+        const uint64_t ntiles = all_tiles - base < per ? all_tiles - base : per;
+        const unsigned grid = grid_for(ntiles, c.grid_cap);
+        const dim3 g(grid), b(TH);
+        const uint32_t x = ((uint64_t)grid == ntiles && ntiles >= 64) ? want : 0u;
 #define ZBRA_LAUNCH_DECODE(NTV, DIR) \
-    hipLaunchKernelGGL((decode_tiles_kernel<DT, TH, NTV, DIR>), g, b, 0, stream, plans, ts, tmap, nd, ntiles, x)
-    switch ((c.nt & 3) * 2 + (c.direct ? 1 : 0)) {
-        case 0: ZBRA_LAUNCH_DECODE(0, false); break;
-        case 1: ZBRA_LAUNCH_DECODE(0, true); break;
-        case 2: ZBRA_LAUNCH_DECODE(1, false); break;
-        case 3: ZBRA_LAUNCH_DECODE(1, true); break;
-        case 4: ZBRA_LAUNCH_DECODE(2, false); break;
-        case 5: ZBRA_LAUNCH_DECODE(2, true); break;
-        case 6: ZBRA_LAUNCH_DECODE(3, false); break;
-        default: ZBRA_LAUNCH_DECODE(3, true); break;
-    }
+    hipLaunchKernelGGL((decode_tiles_kernel<DT, TH, NTV, DIR>), g, b, 0, stream, plans, ts, tmap, nd, base, ntiles, x)
+        switch ((c.nt & 3) * 2 + (c.direct ? 1 : 0)) {
+            case 0: ZBRA_LAUNCH_DECODE(0, false); break;
+            case 1: ZBRA_LAUNCH_DECODE(0, true); break;
+            case 2: ZBRA_LAUNCH_DECODE(1, false); break;
+            case 3: ZBRA_LAUNCH_DECODE(1, true); break;
+            case 4: ZBRA_LAUNCH_DECODE(2, false); break;
+            case 5: ZBRA_LAUNCH_DECODE(2, true); break;
+            case 6: ZBRA_LAUNCH_DECODE(3, false); break;
+            default: ZBRA_LAUNCH_DECODE(3, true); break;
+        }
 #undef ZBRA_LAUNCH_DECODE
+    }
 }
 
-typedef void (*DecodeLauncher)(const DecodeConfig &, unsigned, hipStream_t, const DecodePlan *, const uint64_t *,
-                               const uint32_t *, uint32_t, uint64_t, uint32_t);
+typedef void (*DecodeLauncher)(const DecodeConfig &, hipStream_t, const DecodePlan *, const uint64_t *, const uint32_t *,
+                               uint32_t, uint64_t, uint32_t);
 struct DecodeShape { int tile, threads; DecodeLauncher fn; };
 static const DecodeShape kDecodeShapes[] = {  // the default and the alternatives it was measured against
     {2048, 512, launch_decode_t<2048, 512>}, {2048, 256, launch_decode_t<2048, 256>}, {1024, 256, launch_decode_t<1024, 256>},
@@ -171,10 +184,14 @@ static inline uint32_t decode_tile_order(uint64_t encoded_bytes, uint64_t values
 static void launch_decode(hipStream_t stream, const DecodePlan *plans, const uint64_t *ts, const uint32_t *tmap, uint32_t nd,
                           uint64_t ntiles, uint32_t order) {
     const DecodeConfig &c = decode_config();
-    g_decode_fn(c, grid_for(ntiles, c.grid_cap), stream, plans, ts, tmap, nd, ntiles, order);
+    g_decode_fn(c, stream, plans, ts, tmap, nd, ntiles, order);
 }
 
 constexpr unsigned STREAM_GRID_CAP = 256 * 8;
+
+// Arrays one device submission handles at once: its per-array launches (one workgroup of up to
+// 1024 lanes per array) stay far inside the work-items of a dispatch, and its tables stay small.
+constexpr size_t MAX_BATCH_ARRAYS = (size_t)1 << 20;
 
 // ZBRA_HIP_ENCODE_BRACKET=0 turns the sampled bracket off: every array then takes the path a
 // failed bracket takes (min/max pass + radix select over the whole array).  Tuning / test aid.
@@ -215,6 +232,13 @@ static int decode_batch_dev(DeviceCtx *ctx, const zbra_array_desc *descs, size_t
         const zbra_array_desc &d = descs[i];
         if (d.count > MAX_COUNT || d.kind > ZBRA_ELEM_U32) return ZBRA_ERR_INVALID_ARG;
         if ((d.len && !d.data) || (d.count && d.len && !d.out)) return ZBRA_ERR_INVALID_ARG;
+    }
+    if (nd > MAX_BATCH_ARRAYS) {  // arrays are independent: a longer table goes down in pieces
+        for (size_t first = 0; first < nd; first += MAX_BATCH_ARRAYS) {
+            const size_t n = nd - first < MAX_BATCH_ARRAYS ? nd - first : MAX_BATCH_ARRAYS;
+            ZBRA_TRY(decode_batch_dev(ctx, descs + first, n, d_results ? d_results + first : nullptr, stream));
+        }
+        return ZBRA_OK;
     }
     if (nd == 1) {
         const uint64_t ntiles = decode_tiles_of(descs[0].count, descs[0].kind);
@@ -353,6 +377,15 @@ static int encode_batch_dev(DeviceCtx *ctx, const EncodeItem *items, size_t nd, 
     for (size_t i = 0; i < nd; i++) {
         if (items[i].n > MAX_COUNT || items[i].kind > KIND_U64_PLAIN) return ZBRA_ERR_INVALID_ARG;
         if (items[i].n && (!items[i].values || (mode == ENCODE_FULL && !frames && !items[i].out))) return ZBRA_ERR_INVALID_ARG;
+    }
+    if (nd > MAX_BATCH_ARRAYS) {
+        // the frames of one call are laid out by one scan over its arrays; plain encodes are independent
+        if (frames) return ZBRA_ERR_INVALID_ARG;
+        for (size_t first = 0; first < nd; first += MAX_BATCH_ARRAYS) {
+            const size_t n = nd - first < MAX_BATCH_ARRAYS ? nd - first : MAX_BATCH_ARRAYS;
+            ZBRA_TRY(encode_batch_dev(ctx, items + first, n, d_results ? d_results + first : nullptr, stream, mode, nullptr));
+        }
+        return ZBRA_OK;
     }
     const bool bracket = encode_bracket_enabled();
     const uint64_t small_max = small_select_keys();
@@ -498,7 +531,9 @@ static int encode_batch_dev(DeviceCtx *ctx, const EncodeItem *items, size_t nd, 
                 // columns 4.70 against 5.03); a single array takes the plain order, which is as fast
                 // at 2^28 rows and 1-4 % faster at 2^27 (pack at width 12: 213 against 221 us,
                 // raw: 350 against 364).  ZBRA_HIP_PACK_XCD=0|1 forces one or the other.
-                const unsigned gp = grid_for(ntiles, pack_grid_cap());
+                // past the work-items of one dispatch the workgroups take several tiles each, in the plain order
+                const uint64_t pack_most = g_launch_limit / THREADS ? g_launch_limit / THREADS : 1;
+                const unsigned gp = grid_for(ntiles, (uint64_t)pack_grid_cap() < pack_most ? pack_grid_cap() : (unsigned)pack_most);
                 static const int pack_xcd_env = [] { const char *e = getenv("ZBRA_HIP_PACK_XCD"); return e ? atoi(e) : -1; }();
                 const bool pack_xcd = pack_xcd_env >= 0 ? pack_xcd_env != 0 : nd > 1;
                 hipLaunchKernelGGL(enc_pack_kernel, dim3(gp), dim3(THREADS), 0, stream, d_jobs, d_ts, d_map, (uint32_t)nd, ntiles,
@@ -798,8 +833,14 @@ using namespace zbra;
 
 extern "C" {
 
-// Tuning hook (not part of the ABI, not declared in the header): switches the decode kernel shape
-// at run time so that variants can be timed interleaved in one process.  Not thread-safe.
+// Tuning hooks (not part of the ABI, not declared in the header).  Not thread-safe.
+// zbra_tuning_set_launch_limit: work-items per dispatch (0 = the hardware's 2^32 - 1).
+// zbra_tuning_set_decode_variant: switches the decode kernel shape at run time so that variants can
+// be timed interleaved in one process.
+int zbra_tuning_set_launch_limit(uint64_t work_items) {
+    g_launch_limit = work_items && work_items < 0xFFFFFFFFull ? work_items : 0xFFFFFFFFull;
+    return 0;
+}
 int zbra_tuning_set_decode_variant(int tile, int threads, int nt, int direct, int xcd) {
     (void)decode_config();
     g_decode_cfg.xcd = xcd;

@@ -355,17 +355,20 @@ __device__ __forceinline__ void decode_tile(const DecodePlan &p, uint64_t tile_i
     }
 }
 
-// Batched submission: plans come from plan_decode_batch_kernel.
+// Batched submission: plans come from plan_decode_batch_kernel.  A launch covers the tiles
+// [tile_base, tile_base + ntiles) of the submission: the host cuts a submission whose one
+// workgroup per tile would pass the 2^32 work-items of a dispatch into several launches.
 template <int DT, int TH, int NT, bool DIRECT>
 __global__ __launch_bounds__(TH) void decode_tiles_kernel(const DecodePlan *__restrict__ plans,
                                                           const uint64_t *__restrict__ tile_start,
                                                           const uint32_t *__restrict__ tile_map, uint32_t nd,
-                                                          uint64_t ntiles, uint32_t xcd_chunked) {
+                                                          uint64_t tile_base, uint64_t ntiles, uint32_t xcd_chunked) {
     // u32 outputs are half as wide, so their tiles hold twice the values (same bytes written)
     __shared__ __attribute__((aligned(16))) uint32_t lds[lds_dwords<2 * DT>()];
     // xcd_chunked implies gridDim.x == ntiles: exactly one trip through the loop
-    uint64_t t = xcd_chunked == 1 ? xcd_chunked_tile(blockIdx.x, ntiles) : xcd_chunked ? xcd_grouped_tile(blockIdx.x, ntiles, xcd_chunked) : blockIdx.x;
-    for (; t < ntiles; t += gridDim.x) {
+    uint64_t i = xcd_chunked == 1 ? xcd_chunked_tile(blockIdx.x, ntiles) : xcd_chunked ? xcd_grouped_tile(blockIdx.x, ntiles, xcd_chunked) : blockIdx.x;
+    for (; i < ntiles; i += gridDim.x) {
+        const uint64_t t = tile_base + i;
         const uint32_t a = nd > 1 ? tile_map[t] : 0;
         const DecodePlan p = plans[a];
         decode_tile<DT, TH, NT, DIRECT>(p, t - tile_start[a], lds);
