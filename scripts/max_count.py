@@ -58,6 +58,27 @@ def roundtrip(name, dt, fn, width_in):
 # 1. int64 values below 100 + a slow drift: width 7 or 8
 v, enc, elen = roundtrip("int64 encode + decode", torch.int64, lambda i: (i * 2654435761) % 97 + (i >> 31), (7, 8))
 
+# 1b. the host-pointer calls on the same array: pageable memory in, pageable memory out
+import ctypes as C
+
+import numpy as np
+
+v_h = np.empty(N, dtype=np.int64)
+for i0 in range(0, N, STEP):
+    v_h[i0:i0 + STEP] = v[i0:i0 + STEP].cpu().numpy()
+e_h = np.empty(elen + 4096, dtype=np.uint8)
+got = C.c_size_t(0)
+st = _lib.lib.zbra_hip_encode_i64(v_h.ctypes.data_as(C.c_void_p), N, e_h.ctypes.data_as(C.c_void_p), e_h.size, C.byref(got))
+assert st == 0 and got.value == elen, (st, got.value)
+assert all(np.array_equal(e_h[i0:min(elen, i0 + STEP)], enc[i0:min(elen, i0 + STEP)].cpu().numpy()) for i0 in range(0, elen, STEP))
+d_h = np.empty(N, dtype=np.int64)
+cnt = C.c_size_t(0)
+st = _lib.lib.zbra_hip_decode_i64(e_h.ctypes.data_as(C.c_void_p), elen, N, d_h.ctypes.data_as(C.c_void_p), C.byref(cnt))
+assert st == 0 and cnt.value == N, (st, cnt.value)
+assert all(np.array_equal(d_h[i0:i0 + STEP], v_h[i0:i0 + STEP]) for i0 in range(0, N, STEP))
+print(json.dumps({"check": "host-pointer int64 encode + decode", "n": N, "ok": True}), flush=True)
+del v_h, e_h, d_h
+
 # 2. the same bytes as lengths: offsets[i + 1] = offsets[i] + v[i]
 offs = torch.empty(N + 1, dtype=torch.int64, device=dev)
 device.decode_offsets_dev(enc, N, offs, None, length=elen)
