@@ -262,3 +262,33 @@ def test_walker_fuzz_under_sanitizers(tmp_path):
     r = subprocess.run([exe, "4000", "7"], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "4000 valid images indexed exactly" in r.stdout
+
+
+@pytest.mark.gpu
+def test_frames_that_produce_nothing():
+    """decompress_int_array returns an empty Vec for empty data and for packed_len == 0 whatever the
+    frame's count says (compression.rs:296-298, 182-184): the reader hands back empty vectors and
+    sizes nothing by such a count (a corrupt frame may say 2^32 - 1)."""
+    from zbra_amd import binary as zb
+
+    class HollowCodec:
+        @staticmethod
+        def compress_int_array(values):
+            return bytes(8) + (0).to_bytes(4, "little")      # midpoint 0, packed_len 0
+
+    real = column("narrow", 1000, 3)
+    blocks = [zb.Block(9, zb.ArrayTable(zb.Struct([("a", zb.Int(np.arange(9, dtype=np.int64)))]))),
+              zb.Block(1000, zb.ArrayTable(zb.Int(real)))]
+    hollow = bytearray(zb.BinaryFile("{}", blocks[:1]).to_bytes(HollowCodec))
+    info, arrays = zb.file_index(bytes(hollow))
+    assert info.n_arrays == 1 and arrays[0].count == 9 and arrays[0].len == 12
+    back = zb.BinaryFile.from_bytes(bytes(hollow))
+    assert back.blocks[0].table.column.fields[0][1].values.size == 0
+    # an empty frame whose count field says 2^32 - 1, next to a real array
+    img = bytearray(zb.BinaryFile("{}", [zb.Block(0, zb.ArrayTable(zb.Int(np.zeros(0, dtype=np.int64)))), blocks[1]]).to_bytes())
+    info, arrays = zb.file_index(bytes(img))
+    assert arrays[0].count == 0 and arrays[0].len == 0
+    img[arrays[0].offset - 8:arrays[0].offset - 4] = (0xFFFFFFFF).to_bytes(4, "little")
+    back = zb.BinaryFile.from_bytes(bytes(img))
+    assert back.blocks[0].table.column.values.size == 0
+    assert np.array_equal(back.blocks[1].table.column.values, real)

@@ -363,17 +363,18 @@ def file_decode(image, info, arrays):
     (int64, or uint32 for enum tags) in file order."""
     buf = np.frombuffer(image, dtype=np.uint8)
     n = info.n_arrays
-    outs = [np.empty(arrays[i].count, dtype=np.uint32 if arrays[i].kind == _lib.ELEM_U32 else np.int64) for i in range(n)]
-    ptrs = (C.c_void_p * max(1, n))(*[o.ctypes.data if o.size else None for o in outs])
+    # decompress_int_array returns an empty Vec for empty data and for packed_len == 0 whatever
+    # count says (compression.rs:296-298, :182-184): the device writes nothing there, so the buffer
+    # is sized by what the header says will come (a corrupt frame's count allocates nothing);
+    # a malformed E raises here what the decode would raise
+    sizes = [_gpu.decoded_count(buf[arrays[i].offset:arrays[i].offset + arrays[i].len], arrays[i].count) for i in range(n)]
+    outs = [np.empty(sizes[i], dtype=np.uint32 if arrays[i].kind == _lib.ELEM_U32 else np.int64) for i in range(n)]
+    nothing = np.empty(2, dtype=np.int64)  # where an array that produces no value "goes": never written
+    ptrs = (C.c_void_p * max(1, n))(*[o.ctypes.data if o.size else nothing.ctypes.data for o in outs])
     statuses = (C.c_int * max(1, n))()
     st = lib.zbra_hip_file_decode(buf.ctypes.data_as(C.c_void_p), buf.size, arrays, n, ptrs, statuses)
     if st:
         _gpu._raise(st)
-    # decompress_int_array returns an empty Vec for empty data and for packed_len == 0 whatever
-    # count says (compression.rs:296-298, :182-184): the device wrote nothing there
-    for i in range(n):
-        a = arrays[i]
-        outs[i] = outs[i][:_gpu.decoded_count(buf[a.offset:a.offset + a.len], a.count)]
     return outs
 
 
