@@ -11,7 +11,10 @@ Measures
        (64 GB of image + 164 GB of values fit the 288 GB of one MI355X), and
   (ii) image in pageable host memory -> values in host memory, one zbra_hip_file_decode call per
        group of `--blocks` Blocks into a REUSED set of output buffers (the values are consumed and
-       not retained: 164 GB of them do not fit beside the image in the box's memory share).
+       not retained: 164 GB of them do not fit beside the image in the box's memory share), and
+  (iii) the write path at the same size: the file's 4896 int arrays in host memory (the distinct
+       Blocks' vectors, repeated as in the file) -> their frames in host memory through
+       zbra_hip_encode_frames, checked against the frames of the image.
 If the device or host does not have the memory, the file is scaled down and the scale is stated."""
 import argparse
 import ctypes as C
@@ -34,6 +37,7 @@ def main():
     ap.add_argument("--rows-log2", type=int, default=22)
     ap.add_argument("--reps", type=int, default=5)
     ap.add_argument("--skip-host", action="store_true")
+    ap.add_argument("--skip-write", action="store_true")
     ap.add_argument("--group-mult", type=int, nargs="+", default=[1], help="host-to-host calls take this many x --blocks Blocks each")
     args = ap.parse_args()
     import torch
@@ -87,8 +91,8 @@ def main():
     print(f"# image built in {t_img:.1f} s; index: {na} int arrays in {info.block_count} Blocks", flush=True)
 
     line = {}
-    # (ii) runs first: freeing the 228 GB of part (i) leaves the driver unmapping memory for seconds,
-    # and host copies that run meanwhile take twice as long
+    # (ii) and (iii) run first: freeing the 228 GB of part (i) leaves the driver unmapping memory for
+    # seconds, and host copies that run meanwhile take twice as long
     # -- (ii) host image -> host values, group by group into reused buffers ----------------------
     if not args.skip_host:
         FileArray = type(arrays[0])
@@ -119,10 +123,33 @@ def main():
                 "link_GBps_both_directions": round((total + out_bytes) / best / 1e9, 2),
                 "call_ms_min_median_max": [round(calls[0] * 1e3, 1), round(calls[len(calls) // 2] * 1e3, 1), round(calls[-1] * 1e3, 1)]})
             del h_outs
+    # -- (iii) the write path at the same size: the file's int arrays (host memory) -> its frames ---
+    if not args.skip_host and not args.skip_write:
+        frames_of_base = [bytes(base[barrays[k].offset - 8: barrays[k].offset + barrays[k].len]) for k in range(per)]
+        del img, img_p                                  # 64 GB back before the frame buffer is allocated
+        img = None
+        items = [(cols[k % per].ctypes.data, n, 0, 0, _lib.ELEM_I64) for k in range(na)]  # the 24 Blocks' vectors, repeated as in the file
+        edescs = device.make_encode_descs(items)
+        room = sum(len(f) for f in frames_of_base) * reps_of_body
+        out = np.empty(room + 4096, dtype=np.uint8)
+        offs = np.zeros(na + 1, dtype=np.uint64)
+        statuses = (C.c_int * na)()
+        t0 = time.perf_counter()
+        st = _lib.lib.zbra_hip_encode_frames(edescs, na, out.ctypes.data_as(C.c_void_p), out.size, offs.ctypes.data_as(C.POINTER(C.c_uint64)), statuses)
+        t_enc = time.perf_counter() - t0
+        assert st == 0 and int(offs[na]) == room, (st, int(offs[na]), room)
+        group = int(offs[per])
+        first = out[:group].tobytes()
+        assert first == b"".join(frames_of_base)
+        assert all(out[r * group:(r + 1) * group].tobytes() == first for r in range(1, reps_of_body, max(1, reps_of_body // 8)))
+        line["write_path"] = {"arrays": na, "values_GB": round(out_bytes / 1e9, 1), "frames_GB": round(room / 1e9, 2), "s": round(t_enc, 3),
+                              "values_GBps": round(out_bytes / t_enc / 1e9, 2),
+                              "note": "zbra_hip_encode_frames, host values -> host frames, first call of the process (buffers fresh)"}
+        del out, first
     # -- (i) device-resident: the whole file in one batched submission ---------------------------
     d_img = torch.empty(total, dtype=torch.uint8, device=dev)
     d_img[:base.size].copy_(torch.from_numpy(base))
-    d_img[hdr - 4:hdr].copy_(torch.from_numpy(img[hdr - 4:hdr]))
+    d_img[hdr - 4:hdr].copy_(torch.from_numpy(np.frombuffer(np.uint32(args.blocks * reps_of_body).tobytes(), dtype=np.uint8).copy()))
     for r in range(1, reps_of_body):                    # the same bytes the host image holds
         d_img[hdr + r * body: hdr + (r + 1) * body].copy_(d_img[hdr:hdr + body])
     d_out = torch.empty(int(info.total_values), dtype=torch.int64, device=dev)
