@@ -6,9 +6,11 @@ two layers:
   * "hand": midpoint / bit width / encoded length (and, for short vectors, the
     full hex) derived BY HAND from the text of zbra-core/src/compression.rs —
     typed in below, not computed;
-  * "hex": the full encoded bytes, written only when the C restatement and the
-    numpy restatement produce identical bytes that also satisfy the hand layer.
-The script refuses to write the file if any of the three disagree.
+  * "hex": the full encoded bytes, written only when the C restatement, the
+    numpy restatement and the big-integer statement of the layout
+    (oracle/zbra_oracle_spec.py) produce identical bytes that also satisfy the
+    hand layer.
+The script refuses to write the file if any of them disagree.
 
 Inputs come from the reference's own tests:
   compression.rs:339,347,355,363           unit-test vectors
@@ -29,6 +31,7 @@ sys.path.insert(0, ROOT)
 
 from oracle import zbra_oracle_c as oc  # noqa: E402
 from oracle import zbra_oracle_np as on  # noqa: E402
+from oracle import zbra_oracle_spec as osp  # noqa: E402
 
 I64_MIN, I64_MAX = -(1 << 63), (1 << 63) - 1
 
@@ -123,6 +126,8 @@ def main():
         ec = oc.compress_int_array(values)
         en = on.compress_int_array(values)
         assert ec == en, f"{name}: C and numpy restatements disagree"
+        assert ec == osp.compress_int_array(values), f"{name}: the big-integer statement of the layout disagrees"
+        assert osp.decompress_int_array(ec, len(values)) == values, name
         got_mid = int.from_bytes(ec[0:8], "little", signed=True)
         assert got_mid == mid, (name, got_mid, mid)
         assert ec[12] == w, (name, ec[12], w)
@@ -159,6 +164,7 @@ def main():
                               "hand": {"hex": hand_hex},
                               "hex": oc.compress_int_array(values).hex()})
         assert oc.compress_int_array(values).hex() == hand_hex == on.compress_int_array(values).hex(), name
+        assert osp.compress_int_array(values).hex() == hand_hex, name
     image = b"".join(p.encode() if kind == "ascii" else bytes.fromhex(p) for kind, p in FILE_IMAGE)
     assert len(image) == FILE_IMAGE_LEN, len(image)
     out["file"] = [{"name": "T", "origin": "zbra-core/src/binary.rs:708-741 (test_binary_roundtrip_simple)",

@@ -159,3 +159,31 @@ def test_timed_baseline_with_stable_sort_gives_the_oracles_bytes(kind):
         buf = np.empty(13 + 8 * n, dtype=np.uint8)
         got = oc.compress_int_array_stable_sort_into(np.ascontiguousarray(v), buf)
         assert buf[:got].tobytes() == want, (kind, n)
+
+
+def test_big_integer_statement_of_the_layout(golden):
+    """A third formulation with no bit buffer (oracle/zbra_oracle_spec.py: the payload is
+    sum(z[i] << (i * w)) as little-endian bytes) gives the bytes of every golden vector, the 643
+    bytes of vector M included, and of proptest-shaped random arrays (compression.rs:378-406)."""
+    from oracle import zbra_oracle_spec as osp
+    for vec in golden["pipeline"] + golden["stages"]:
+        values = [int(v) for v in vec["values"]]
+        assert osp.compress_int_array(values).hex() == vec["hex"], vec["name"]
+        assert osp.decompress_int_array(bytes.fromhex(vec["hex"]), len(values)) == values, vec["name"]
+    rng = np.random.default_rng(2026)
+    for trial in range(300):
+        n = int(rng.integers(0, 100))
+        shape = trial % 4
+        if shape == 0:
+            v = rng.integers(-(1 << 63), (1 << 63) - 1, n, dtype=np.int64, endpoint=True)   # any::<i64>()
+        elif shape == 1:
+            v = rng.integers(0, 1000, n, dtype=np.int64)                                      # 0..1000
+        elif shape == 2:
+            bits = int(rng.integers(1, 63))
+            v = rng.integers(-(1 << bits), 1 << bits, n, dtype=np.int64) + int(rng.integers(-(1 << 40), 1 << 40))
+        else:
+            v = np.where(rng.integers(0, 2, n) == 0, np.int64(-(1 << 63)), np.int64((1 << 63) - 1))  # wrap-around in the deltas
+        e = oc.compress_int_array(v)
+        assert e == osp.compress_int_array(v.tolist()), (trial, v.tolist())
+        assert e == on.compress_int_array(v), trial
+        assert osp.decompress_int_array(e, n) == v.tolist(), trial
