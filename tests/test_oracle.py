@@ -93,6 +93,12 @@ def test_reference_pipeline_assertions(name, o):
     assert ts.size * 8 / len(packed) > 1.5
     e = o.compress_int_array(ts)
     assert ts.size * 8 / len(e) > 1.5
+    # the figures docs/compression-pipeline.md:119-127 states for this week of hourly timestamps:
+    # 29-bit deltas, 30-bit zig-zag values, 30 bits per value, "~53% compression from bit-packing alone"
+    assert int(np.abs(d).max()).bit_length() == 29 and int(z.max()).bit_length() == 30 and packed[0] == 30
+    assert round(100 * (1 - (len(packed) - 1) / (ts.size * 8))) == 53
+    # and docs/compression-pipeline.md:77-82 for its three-value example: 23 bits instead of 64, "~64% size reduction"
+    assert round(100 * (1 - o.bp64_pack(np.array([7199999, 0, 6400000], dtype=np.uint64))[0] / 64)) == 64
     # tests/compression-pipeline.rs:93-121
     small = o.bp64_pack(np.arange(64, dtype=np.uint64) * 1000)
     large = o.bp64_pack((1 << 40) + np.arange(64, dtype=np.uint64))
