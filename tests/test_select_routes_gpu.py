@@ -4,7 +4,8 @@ median comes from a full sort (compression.rs:58-68).  Shapes: a wide bracket wh
 after one counted digit; a candidate list that overflows (two far-apart values, half each); a run of
 one value at the median of otherwise wide data; a dense cluster of different values at the median
 of wide data (which no level resolves: the finishing workgroup reads on, digit by digit); sorted
-wide data; u32 values over their whole range."""
+wide data; u32 values over their whole range; brackets of a few keys, dense (most of the values
+inside: per-lane counting columns) and sparse (shared histogram)."""
 import os
 import subprocess
 import sys
@@ -54,11 +55,15 @@ def _shape(name, n, seed):
         return rng.choice(np.array([-(1 << 63), (1 << 63) - 1, 0, -1, 1], dtype=np.int64), n)
     if name == "min_max_only":      # v - mid wraps for every value: width 1 (compression.rs:60-68 with b - a = -1)
         return np.where(rng.integers(0, 2, n) == 0, -(1 << 63), (1 << 63) - 1).astype(np.int64)
+    if name == "few_keys_dense":    # a bracket of three or four keys that holds most of the values: counted in per-lane columns
+        return 1000 + rng.choice(np.array([0, 1, 2, 3], dtype=np.int64), n, p=[0.45, 0.03, 0.03, 0.49])
+    if name == "few_keys_sparse":   # 48 equally likely values: a bracket of a few keys with a few per cent of the values, shared histogram
+        return -5000 + rng.integers(0, 48, n, dtype=np.int64)
     raise KeyError(name)
 
 
 SHAPES = ["wide_uniform", "wide_40", "two_far", "three_far", "popular_in_wide", "cluster_in_wide", "sorted_wide", "extremes_mix",
-          "min_max_only"]
+          "min_max_only", "few_keys_dense", "few_keys_sparse"]
 
 
 @pytest.fixture(scope="module")

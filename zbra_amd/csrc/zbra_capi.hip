@@ -90,14 +90,15 @@ static uint64_t g_launch_limit = 0xFFFFFFFFull;
 
 template <int DT, int TH>
 static void launch_decode_t(const DecodeConfig &c, hipStream_t stream, const DecodePlan *plans, const uint64_t *ts,
-                            const uint32_t *tmap, uint32_t nd, uint64_t all_tiles, uint32_t order) {
+                            const uint32_t *tmap, uint32_t nd, uint64_t first_tile, uint64_t all_tiles, uint32_t order) {
     // c.xcd: 2 = the order the caller worked out (decode_tile_order); anything else forces that order (tuning)
     const uint32_t want = c.xcd == 2 ? order : (uint32_t)c.xcd;
     // tiles per launch: a multiple of 8 (whole rounds of the XCDs) within the dispatch limit
     uint64_t per = g_launch_limit / TH & ~7ull;
     if (per == 0) per = 8;
-    for (uint64_t base = 0; base < all_tiles; base += per) {
-        const uint64_t ntiles = all_tiles - base < per ? all_tiles - base : per;
+    for (uint64_t done = 0; done < all_tiles; done += per) {
+        const uint64_t base = first_tile + done;
+        const uint64_t ntiles = all_tiles - done < per ? all_tiles - done : per;
         const unsigned grid = grid_for(ntiles, c.grid_cap);
         const dim3 g(grid), b(TH);
         const uint32_t x = ((uint64_t)grid == ntiles && ntiles >= 64) ? want : 0u;
@@ -118,7 +119,7 @@ static void launch_decode_t(const DecodeConfig &c, hipStream_t stream, const Dec
 }
 
 typedef void (*DecodeLauncher)(const DecodeConfig &, hipStream_t, const DecodePlan *, const uint64_t *, const uint32_t *,
-                               uint32_t, uint64_t, uint32_t);
+                               uint32_t, uint64_t, uint64_t, uint32_t);
 struct DecodeShape { int tile, threads; DecodeLauncher fn; };
 static const DecodeShape kDecodeShapes[] = {  // the default and the alternatives it was measured against
     {2048, 512, launch_decode_t<2048, 512>}, {2048, 256, launch_decode_t<2048, 256>}, {1024, 256, launch_decode_t<1024, 256>},
@@ -183,8 +184,65 @@ static inline uint32_t decode_tile_order(uint64_t encoded_bytes, uint64_t values
 
 static void launch_decode(hipStream_t stream, const DecodePlan *plans, const uint64_t *ts, const uint32_t *tmap, uint32_t nd,
                           uint64_t ntiles, uint32_t order) {
-    const DecodeConfig &c = decode_config();
-    g_decode_fn(c, stream, plans, ts, tmap, nd, ntiles, order);
+    g_decode_fn(decode_config(), stream, plans, ts, tmap, nd, 0, ntiles, order);
+}
+
+// Narrow submissions (every array at most g_warm_bits encoded bits per value, g_warm_min_bytes or more
+// in all) are decoded in chunks of about g_warm_bytes packed bytes: warm_tiles_kernel reads a
+// chunk's packed bytes into the memory-side cache, then the tile kernel decodes it with plain
+// loads and without LDS (each lane reads the dwords that hold its own values; lanes overlap, which
+// the caches now absorb).  Measured with the caches emptied before every launch (scripts/ab_decode_cold.py,
+// profiles/r02_ab_decode_warm.txt): 2^27 rows of width 2: 0.214 -> 0.171 ms, 2^28 rows of width 4: 0.408 ->
+// 0.354, of width 6: 0.406 -> 0.385; from width 7 up the warm-up costs what it saves, and so it does for
+// u32 outputs from width 4 up (2^29 tags of width 4: 0.403 -> 0.446 ms), whose limit is half the width.
+// ZBRA_HIP_DECODE_WARM=0 turns it off; zbra_tuning_set_decode_warm changes chunk and width limit.
+static uint64_t g_warm_bytes = [] { const char *e = getenv("ZBRA_HIP_DECODE_WARM"); return e && atoi(e) == 0 ? (uint64_t)0 : (uint64_t)64 << 20; }();
+static uint32_t g_warm_bits = 6;
+static uint64_t g_warm_min_bytes = (uint64_t)8 << 20;
+
+struct WarmPlan {
+    bool on = false;
+    uint64_t tiles_per_chunk = 0;
+    uint32_t tiles_per_wg = 1;
+};
+static WarmPlan warm_plan_for(const zbra_array_desc *descs, size_t nd, uint64_t ntiles, uint64_t all_bytes) {
+    WarmPlan wp;
+    if (!g_warm_bytes || !ntiles || all_bytes < g_warm_min_bytes || decode_config().tile != 2048 || decode_config().direct) return wp;
+    for (size_t i = 0; i < nd; i++) {
+        const zbra_array_desc &d = descs[i];
+        if (d.count < 8 || d.len <= 13) continue;  // too short to matter (or to tell)
+        // bits per value as the frame's length says them: exact for a well-formed E (a wrong guess costs time, nothing else)
+        // u32 outputs are half as wide: the same packed bytes buy half the output, so half the width pays
+        const uint64_t bits = (d.len - 13) * 8 / d.count * (d.kind == ZBRA_ELEM_U32 ? 2 : 1);
+        if (bits < 1 || bits > g_warm_bits) return wp;
+    }
+    wp.on = true;
+    const uint64_t tile_bytes = all_bytes / ntiles ? all_bytes / ntiles : 1;
+    wp.tiles_per_chunk = (g_warm_bytes / tile_bytes) & ~7ull;
+    if (wp.tiles_per_chunk < 64) wp.tiles_per_chunk = 64;
+    const uint64_t per_wg = 65536 / tile_bytes;
+    wp.tiles_per_wg = (uint32_t)(per_wg < 1 ? 1 : per_wg > 256 ? 256 : per_wg);
+    return wp;
+}
+
+// Tile kernel launches of one submission: all its tiles at once, or chunk by chunk behind the
+// warm-up of each chunk.
+static void launch_decode_submission(hipStream_t stream, const DecodePlan *plans, const uint64_t *ts, const uint32_t *tmap, uint32_t nd,
+                                     uint64_t ntiles, uint32_t order, const WarmPlan &wp) {
+    DecodeConfig c = decode_config();
+    if (!wp.on) {
+        g_decode_fn(c, stream, plans, ts, tmap, nd, 0, ntiles, order);
+        return;
+    }
+    c.nt = 2;      // plain loads (they hit what the warm-up left), nontemporal stores
+    c.direct = 1;
+    for (uint64_t base = 0; base < ntiles; base += wp.tiles_per_chunk) {
+        const uint64_t n = ntiles - base < wp.tiles_per_chunk ? ntiles - base : wp.tiles_per_chunk;
+        const unsigned grid = (unsigned)((n + wp.tiles_per_wg - 1) / wp.tiles_per_wg);
+        hipLaunchKernelGGL((warm_tiles_kernel<2048>), dim3(grid), dim3(256), 0, stream, plans, ts, tmap, nd, base, n, wp.tiles_per_wg,
+                           g_warm_bits > 31 ? 31u : g_warm_bits);
+        g_decode_fn(c, stream, plans, ts, tmap, nd, base, n, order);
+    }
 }
 
 constexpr unsigned STREAM_GRID_CAP = 256 * 8;
@@ -248,7 +306,9 @@ static int decode_batch_dev(DeviceCtx *ctx, const zbra_array_desc *descs, size_t
         uint64_t *tile_start = (uint64_t *)((char *)s->dev + 64);
         hipLaunchKernelGGL(plan_decode_one_kernel, dim3(1), dim3(64), 0, stream, descs[0], ntiles, plan, tile_start,
                            d_results);
-        if (ntiles) launch_decode(stream, plan, tile_start, nullptr, 1u, ntiles, decode_tile_order(descs[0].len, descs[0].count, 1));
+        if (ntiles)
+            launch_decode_submission(stream, plan, tile_start, nullptr, 1u, ntiles, decode_tile_order(descs[0].len, descs[0].count, 1),
+                                     warm_plan_for(descs, 1, ntiles, descs[0].len));
         int st = hip_status(hipGetLastError());
         int st2 = ctx->release(s, stream);
         return st != ZBRA_OK ? st : st2;
@@ -278,7 +338,9 @@ static int decode_batch_dev(DeviceCtx *ctx, const zbra_array_desc *descs, size_t
         uint32_t *d_map = (uint32_t *)((char *)s->dev + off_map);
         hipLaunchKernelGGL(plan_decode_batch_kernel, dim3((unsigned)nd), dim3(256), 0, stream, d_descs, (uint32_t)nd, d_ts,
                            d_plans, d_map, d_results);
-        if (ntiles) launch_decode(stream, d_plans, d_ts, d_map, (uint32_t)nd, ntiles, decode_tile_order(all_bytes, all_values, nd));
+        if (ntiles)
+            launch_decode_submission(stream, d_plans, d_ts, d_map, (uint32_t)nd, ntiles, decode_tile_order(all_bytes, all_values, nd),
+                                     warm_plan_for(descs, nd, ntiles, all_bytes));
         st = hip_status(hipGetLastError());
     }
     int st2 = ctx->release(s, stream);
@@ -835,8 +897,16 @@ extern "C" {
 
 // Tuning hooks (not part of the ABI, not declared in the header).  Not thread-safe.
 // zbra_tuning_set_launch_limit: work-items per dispatch (0 = the hardware's 2^32 - 1).
+// zbra_tuning_set_decode_warm: packed bytes per warmed chunk (0 = off), widest array that takes
+// the warm-up path, smallest submission that does (defaults 64 MiB, 6 bits, 8 MiB).
 // zbra_tuning_set_decode_variant: switches the decode kernel shape at run time so that variants can
 // be timed interleaved in one process.
+int zbra_tuning_set_decode_warm(uint64_t chunk_bytes, uint32_t max_bits, uint64_t min_bytes) {
+    g_warm_bytes = chunk_bytes;
+    g_warm_bits = max_bits;
+    g_warm_min_bytes = min_bytes;
+    return 0;
+}
 int zbra_tuning_set_launch_limit(uint64_t work_items) {
     g_launch_limit = work_items && work_items < 0xFFFFFFFFull ? work_items : 0xFFFFFFFFull;
     return 0;

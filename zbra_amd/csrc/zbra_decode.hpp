@@ -278,6 +278,61 @@ __device__ __forceinline__ void tile_packed_direct(const DecodePlan &p, uint64_t
     }
 }
 
+// The same for u32 outputs of widths up to 8 (enum tags): a lane's four values lie inside the 32
+// bits that start at its first value, which two dwords hold.
+typedef u32x2 u32x2_a4 __attribute__((aligned(4)));  // two dwords at any dword address
+constexpr uint32_t DIRECT_U32_MAX_W = 8;
+
+template <int DT, int TH, int NT>
+__device__ __forceinline__ void tile_packed_direct_u32(const DecodePlan &p, uint64_t v0, uint32_t nv) {
+    const uint32_t tid = threadIdx.x;
+    const uint32_t w = p.width;
+    const uintptr_t P = (uintptr_t)p.payload;
+    const uintptr_t A = P + ((v0 * w) >> 3);       // tile start, a byte of the payload
+    const uintptr_t A4 = A & ~(uintptr_t)3;
+    const uint32_t base_bits = (uint32_t)(A - A4) * 8u;
+    const uint64_t last_dword = ((P + p.avail - 1) - A4) >> 2;  // last dword (relative to A4) that holds a payload byte
+    const uint32_t need_dwords = ((base_bits + nv * w) >> 5) + 1u;  // >= the highest dword index any lane loads
+    const bool interior = (uint64_t)need_dwords <= last_dword;             // uniform
+    const ZBRA_GLOBAL uint32_t *src = gptr<uint32_t>(A4);
+    const uint32_t mask = (1u << w) - 1u;
+    ZBRA_GLOBAL uint32_t *out = gptr_mut<uint32_t>(p.out) + v0;
+    const uint32_t mid = (uint32_t)p.midpoint;
+    constexpr int ITS = DT / (TH * 4) > 0 ? DT / (TH * 4) : 1;
+#pragma unroll
+    for (int it = 0; it < ITS; ++it) {
+        const uint32_t j = it * TH * 4 + tid * 4;
+        if (j < nv) {
+            const uint32_t b = base_bits + j * w;
+            const uint32_t idx = b >> 5, s = b & 31u;
+            uint32_t d0, d1;
+            if (interior) {
+                const ZBRA_GLOBAL u32x2_a4 *q = (const ZBRA_GLOBAL u32x2_a4 *)(src + idx);
+                u32x2 t;
+                if constexpr (NT & 1) t = __builtin_nontemporal_load(q);
+                else t = *q;
+                d0 = t.x; d1 = t.y;
+            } else {
+                d0 = src[idx];
+                d1 = (uint64_t)idx + 1 <= last_dword ? src[idx + 1] : 0u;
+            }
+            const uint32_t x = __builtin_amdgcn_alignbit(d1, d0, s);  // the 32 bits that start at b
+            u32x4 v;
+            v.x = mid + (uint32_t)zigzag_decode32(x & mask);
+            v.y = mid + (uint32_t)zigzag_decode32((x >> w) & mask);
+            v.z = mid + (uint32_t)zigzag_decode32((x >> (2 * w)) & mask);
+            v.w = mid + (uint32_t)zigzag_decode32((x >> (3 * w)) & mask);
+            if (j + 3 < nv) {
+                st_stream<NT>(v, (ZBRA_GLOBAL u32x4 *)(out + j));
+            } else {
+                out[j] = v.x;
+                if (j + 1 < nv) out[j + 1] = v.y;
+                if (j + 2 < nv) out[j + 2] = v.z;
+            }
+        }
+    }
+}
+
 // Raw fallback (width byte >= 32): value i is the u64 at payload + 8*i when all 8 bytes are
 // present, else 0 (compression.rs:195-207).
 template <int DT, int TH, int NT>
@@ -344,7 +399,10 @@ __device__ __forceinline__ void decode_tile(const DecodePlan &p, uint64_t tile_i
     const uint64_t left = p.count - v0;
     const uint32_t nv = left < (uint64_t)tv ? (uint32_t)left : tv;
     if (p.width - 1u < 31u) {
-        if (narrow) tile_packed<2 * DT, TH, NT>(p, v0, nv, lds);
+        if (narrow) {
+            if (DIRECT && p.width <= DIRECT_U32_MAX_W) tile_packed_direct_u32<2 * DT, TH, NT>(p, v0, nv);
+            else tile_packed<2 * DT, TH, NT>(p, v0, nv, lds);
+        }
         else if (DIRECT) tile_packed_direct<DT, TH, NT>(p, v0, nv);
         else tile_packed<DT, TH, NT>(p, v0, nv, lds);
     } else if (p.width == 0) {
@@ -353,6 +411,41 @@ __device__ __forceinline__ void decode_tile(const DecodePlan &p, uint64_t tile_i
         if (narrow) tile_raw<2 * DT, TH, NT>(p, v0, nv);
         else tile_raw<DT, TH, NT>(p, v0, nv);
     }
+}
+
+// Reads the packed bytes of tiles [tile_base, tile_base + ntiles) of a submission with plain loads
+// and throws them away: what it leaves behind is those bytes in the memory-side cache, where the
+// tile kernel that follows finds them at a fraction of the HBM latency.  Worth its time for narrow
+// arrays only (max_width): their packed bytes are few and their decode is bound by how long a wave
+// waits for them.  Workgroup b takes tiles_per_wg consecutive tiles; the tiles of one array are
+// contiguous in memory, so each run of them is one flat sweep of 16-byte chunks (every chunk holds
+// at least one payload byte, hence lies inside a mapped page).
+template <int DT>
+__global__ __launch_bounds__(256) void warm_tiles_kernel(const DecodePlan *__restrict__ plans, const uint64_t *__restrict__ tile_start,
+                                                         const uint32_t *__restrict__ tile_map, uint32_t nd, uint64_t tile_base,
+                                                         uint64_t ntiles, uint32_t tiles_per_wg, uint32_t max_width) {
+    uint64_t t = tile_base + (uint64_t)blockIdx.x * tiles_per_wg;
+    const uint64_t tend = t + tiles_per_wg < tile_base + ntiles ? t + tiles_per_wg : tile_base + ntiles;
+    u32x4 acc = {0, 0, 0, 0};
+    while (t < tend) {  // uniform
+        const uint32_t a = nd > 1 ? tile_map[t] : 0;
+        const DecodePlan p = plans[a];
+        const uint64_t a_first = tile_start[a], a_end = tile_start[a + 1];
+        const uint64_t run_end = a_end < tend ? a_end : tend;  // tiles [t, run_end) belong to array a
+        const uint64_t tv = p.kind == ZBRA_ELEM_U32 ? 2 * DT : DT;
+        const uint64_t v0 = (t - a_first) * tv;
+        if (p.width - 1u < max_width && v0 < p.count) {
+            uint64_t v1 = (run_end - a_first) * tv;
+            if (v1 > p.count) v1 = p.count;
+            const uintptr_t b0 = (uintptr_t)p.payload + ((v0 * p.width) >> 3), b1 = (uintptr_t)p.payload + ((v1 * p.width + 7) >> 3);
+            const uintptr_t a0 = b0 & ~(uintptr_t)15;
+            const uint64_t nchunks = (b1 - a0 + 15) >> 4;
+            const ZBRA_GLOBAL u32x4 *src = gptr<u32x4>(a0);
+            for (uint64_t c = threadIdx.x; c < nchunks; c += 256) acc ^= src[c];
+        }
+        t = run_end;
+    }
+    asm volatile("" ::"v"(acc.x), "v"(acc.y), "v"(acc.z), "v"(acc.w));  // the loads have a use
 }
 
 // Batched submission: plans come from plan_decode_batch_kernel.  A launch covers the tiles

@@ -82,6 +82,8 @@ struct EncodeJob {
     uint64_t *small;     // GATHER_CAP keys gathered by a level for the finishing workgroup (long arrays only)
     uint32_t small_n;
     uint32_t pending;    // 1 = on the list of the many-workgroup levels
+    uint32_t dense_bracket;  // the sample says that a large share of the values lies inside a bracket of few keys (see MICRO_KEYS)
+    uint32_t pad_;
     // smallest / largest key among those whose next digit level L counted (all equal: a run of one
     // value, which needs no further digit)
     unsigned long long match_min[3], match_max[3];
@@ -119,6 +121,7 @@ enum SelectMode : uint32_t {
     SEL_DONE = 3             // midpoint and width already known (small array sorted whole, constant, ...)
 };
 
+constexpr uint32_t MICRO_KEYS = 8;     // brackets of fewer keys than this may be counted in per-lane columns (see SEL_BRACKET_MICRO)
 constexpr int SAMPLE = 4096;          // sample keys of an array (four per lane of the sampling workgroup)
 constexpr int SAMPLE_THREADS = 1024;  // lanes of the sampling workgroup
 constexpr int SAMPLE_MARGIN = 128;    // sample ranks either side: 4 sigma, sigma = sqrt(SAMPLE)/2 = 32
@@ -448,10 +451,25 @@ __global__ __launch_bounds__(SAMPLE_THREADS) void enc_sample_kernel(EncodeJob *_
     const uint64_t r = (uint64_t)(((unsigned __int128)k * sample) / n);  // expected sample rank of a
     const bool has_lo = r >= (uint64_t)margin, has_hi = r + margin < (uint64_t)sample;
     select_two_ranks(key, nvalid, has_lo ? (uint32_t)(r - margin) : 0u, has_hi ? (uint32_t)(r + margin) : sample - 1, &sh, got);
+    const uint64_t lo_b = has_lo ? got[0] : 0, hi_b = has_hi ? got[1] : ~0ull;
+    // how many of the sample's keys lie inside the bracket (ties at its ends make that more than 2 * margin)
+    uint32_t inside = 0;
+#pragma unroll
+    for (int i = 0; i < SAMPLE_PER; i++) inside += (uint32_t)i < nvalid && key[i] >= lo_b && key[i] <= hi_b;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) inside += __shfl_xor(inside, o);
+    __syncthreads();  // select_two_ranks is done with wave_sum
+    if ((threadIdx.x & 63u) == 0) sh.wave_sum[0][threadIdx.x >> 6] = inside;
+    __syncthreads();
     if (threadIdx.x != 0) return;
+    inside = 0;
+    for (uint32_t w = 0; w < SAMPLE_THREADS / 64; w++) inside += sh.wave_sum[0][w];
     job.min_b = got[2]; job.max_b = got[3];  // of the sample: where the bracket pass's minimum and maximum start
-    job.lo_b = has_lo ? got[0] : 0;
-    job.hi_b = has_hi ? got[1] : ~0ull;
+    job.lo_b = lo_b;
+    job.hi_b = hi_b;
+    // A bracket of few keys that holds a large share of the values (more than a tenth of them per
+    // key) is counted in per-lane columns; a sparse one goes to the shared histogram like any other.
+    job.dense_bracket = hi_b - lo_b < (uint64_t)MICRO_KEYS && (uint64_t)inside * 10 > (uint64_t)sample * (hi_b - lo_b + 1);
     job.key_base = job.lo_b;  // keys of a bracket select: (v ^ SIGN) - lo_b
     job.key_bits = bit_length64(job.hi_b - job.lo_b);
     job.passes = (job.key_bits + DIGIT_BITS - 1) / DIGIT_BITS;
@@ -471,7 +489,6 @@ struct BracketAcc {
 // every lane's atomic on the same few addresses, which serialise.  Each lane counts in its own
 // column of the pool instead (key k of lane t at lh[k * THREADS + t]: no two lanes ever meet), and
 // the columns are summed when the run ends.
-constexpr uint32_t MICRO_KEYS = 8;
 static_assert(MICRO_KEYS * THREADS <= (uint32_t)BINS, "the private columns live in the histogram pool");
 constexpr uint32_t SEL_BRACKET_MICRO = 100;  // template tag only: a histogram-mode array with a tiny bracket
 // A bracket of ONE key (more than 6 % of the values are the median: a popular tag, a boolean, a
@@ -568,7 +585,8 @@ __global__ __launch_bounds__(THREADS, ZBRA_BRACKET_WAVES) void enc_bracket_kerne
         // a histogram-mode array with a tiny bracket counts in per-lane columns (see MICRO_KEYS)
         const uint64_t bspan = job.hi_b - job.lo_b;
         const uint32_t mode = job.mode != SEL_BRACKET_HIST || bspan >= (uint64_t)MICRO_KEYS ? job.mode
-                              : bspan == 0 ? SEL_BRACKET_ONE : bspan == 1 ? SEL_BRACKET_TWO : SEL_BRACKET_MICRO;
+                              : bspan == 0 ? SEL_BRACKET_ONE : bspan == 1 ? SEL_BRACKET_TWO
+                              : job.dense_bracket ? SEL_BRACKET_MICRO : (uint32_t)SEL_BRACKET_HIST;
         const void *values = job.values;
         const uint32_t kind = job.kind;
         const uint64_t n = job.n, seg_cap = job.seg_cap;
