@@ -247,6 +247,8 @@ static void launch_decode_submission(hipStream_t stream, const DecodePlan *plans
 
 constexpr unsigned STREAM_GRID_CAP = 256 * 8;
 
+static int g_enum_reverse = -1;  // -1: by size; 0 / 1 force the order of the enum write pass (tuning)
+
 // Arrays one device submission handles at once: its per-array launches (one workgroup of up to
 // 1024 lanes per array) stay far inside the work-items of a dispatch, and its tables stay small.
 constexpr size_t MAX_BATCH_ARRAYS = (size_t)1 << 20;
@@ -907,6 +909,7 @@ int zbra_tuning_set_decode_warm(uint64_t chunk_bytes, uint32_t max_bits, uint64_
     g_warm_min_bytes = min_bytes;
     return 0;
 }
+int zbra_tuning_set_enum_reverse(int r) { g_enum_reverse = r; return 0; }
 int zbra_tuning_set_launch_limit(uint64_t work_items) {
     g_launch_limit = work_items && work_items < 0xFFFFFFFFull ? work_items : 0xFFFFFFFFull;
     return 0;
@@ -1109,8 +1112,10 @@ int zbra_hip_decode_offsets_dev(const uint8_t *d_data, size_t len, size_t count,
         hipLaunchKernelGGL(offsets_scan_chunks_kernel, dim3((unsigned)nchunks), dim3(SCAN_CHUNK), 0, stream, plan, tile_sums, chunk_base);
         hipLaunchKernelGGL(offsets_scan_totals_kernel, dim3(1), dim3(SCAN_CHUNK), 0, stream, plan, chunk_base);
     }
+    // the write pass finds the packed bytes in the memory-side cache (256 MB) if the sums pass left them there:
+    // all of them when they are few enough, else the ones it read last, which a back-to-front pass meets first
     hipLaunchKernelGGL(offsets_write_kernel, dim3((unsigned)(ntiles ? ntiles : 1)), dim3(OFF_THREADS), 0, stream, plan, tile_sums, chunk_base,
-                       d_offsets);
+                       d_offsets, len > ((size_t)208 << 20) ? 1u : 0u);
     int st = hip_status(hipGetLastError());
     int st2 = ctx->release(s, stream);
     return st != ZBRA_OK ? st : st2;
@@ -1154,7 +1159,7 @@ int zbra_hip_enum_rows_dev(const uint32_t *d_tags, size_t n, const uint32_t *var
                 hipLaunchKernelGGL(enum_scan_totals_kernel, dim3(n_variants), dim3(SCAN_CHUNK), 0, stream, nchunks, chunk_base, d_counts);
             }
             hipLaunchKernelGGL(enum_write_kernel, dim3((unsigned)ntiles), dim3(ENUM_THREADS), 0, stream, d_tags, (uint64_t)n, d_vt, n_variants,
-                               ntiles, nchunks, tile_counts, chunk_base, d_variant, d_rank);
+                               ntiles, nchunks, tile_counts, chunk_base, d_variant, d_rank, g_enum_reverse < 0 ? ((uint64_t)n * 4 > ((uint64_t)208 << 20) ? 1u : 0u) : (uint32_t)g_enum_reverse);
         }
         hipLaunchKernelGGL(enum_report_kernel, dim3(1), dim3(64), 0, stream, d_tags, (uint64_t)n, d_bad, d_result);
         st = hip_status(hipGetLastError());

@@ -171,7 +171,11 @@ __global__ __launch_bounds__(ENUM_THREADS) void enum_counts_few_kernel(const uin
             const ZBRA_GLOBAL u32x4 *src = (const ZBRA_GLOBAL u32x4 *)(gptr<uint32_t>(tags) + r0) + lane;
             u32x4 x[ENUM_TILE / 256];
 #pragma unroll
+#ifdef ZBRA_ENUM_NT
             for (int st = 0; st < ENUM_TILE / 256; st++) x[st] = __builtin_nontemporal_load(src + st * 64);
+#else
+            for (int st = 0; st < ENUM_TILE / 256; st++) x[st] = src[st * 64];  // plain: what is read here is read again by the write pass
+#endif
             // variant by variant over the lane's 32 tags: a compare and an add-with-carry per tag
             // and live variant (all tags against all variants with byte-packed counters took
             // three times the vector instructions and bound the kernel: 222 us for 2^28 rows)
@@ -255,11 +259,13 @@ __global__ __launch_bounds__(ENUM_THREADS) void enum_write_kernel(const uint32_t
                                                                    const uint32_t *__restrict__ variant_tags, uint32_t nv, uint64_t ntiles,
                                                                    uint64_t nchunks, const uint64_t *__restrict__ tile_counts,
                                                                    const uint64_t *__restrict__ chunk_base, uint32_t *__restrict__ variant,
-                                                                   uint64_t *__restrict__ rank) {
+                                                                   uint64_t *__restrict__ rank, uint32_t reverse) {
     __shared__ EnumShared sh;
     __shared__ uint64_t start[ENUM_WAVES][ENUM_MAX_VARIANTS];  // rank of the wave's first row of each variant
     enum_setup(sh, variant_tags, nv);
-    const uint64_t tile = blockIdx.x;
+    // back to front when the tags are more than the memory-side cache holds: what the counting pass
+    // read last is what is still there
+    const uint64_t tile = reverse ? gridDim.x - 1 - blockIdx.x : blockIdx.x;
     uint32_t v[ENUM_PER], r[ENUM_PER];
     uint64_t bad = ~0ull;
     enum_wave_rows(sh, tags, tile * ENUM_TILE, n, nv, v, r, bad);
