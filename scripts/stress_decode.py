@@ -74,11 +74,17 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--trials", type=int, default=40)
     ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--warm-all", action="store_true",
+                    help="send every submission down the warm-up route (chunked launches, LDS-free tile kernel) whatever its size and widths")
     args = ap.parse_args()
+    import ctypes as C
+
     import torch
 
     from oracle import zbra_oracle_c as oc
     from zbra_amd import _lib, device
+    if args.warm_all:
+        _lib.lib.zbra_tuning_set_decode_warm(C.c_uint64(64 << 10), C.c_uint32(1 << 30), C.c_uint64(0))  # raw arrays too: their tiles are not warmed, but take the same launches
     total = 0
     for t in range(args.trials):
         total += run_trial(torch, device, _lib, oc, args.seed + t)

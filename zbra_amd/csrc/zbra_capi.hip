@@ -214,7 +214,7 @@ static WarmPlan warm_plan_for(const zbra_array_desc *descs, size_t nd, uint64_t 
         // bits per value as the frame's length says them: exact for a well-formed E (a wrong guess costs time, nothing else)
         // u32 outputs are half as wide: the same packed bytes buy half the output, so half the width pays
         const uint64_t bits = (d.len - 13) * 8 / d.count * (d.kind == ZBRA_ELEM_U32 ? 2 : 1);
-        if (bits < 1 || bits > g_warm_bits) return wp;
+        if (bits > g_warm_bits) return wp;
     }
     wp.on = true;
     const uint64_t tile_bytes = all_bytes / ntiles ? all_bytes / ntiles : 1;
