@@ -138,3 +138,52 @@ def test_default_thresholds_on_a_large_narrow_column(env):
     out32 = torch.empty(n, dtype=torch.int32, device="cuda")
     device.decode_dev(enc, n, out32, None, length=int(r.out_count))
     assert torch.equal(out32.to(torch.int64), v)
+
+
+def test_mixed_batch_puts_narrow_arrays_first(env):
+    """Narrow and wide arrays in one submission: the device sees the narrow ones first (their tiles
+    take the warm-up route, the others the default kernel); results and status words must still
+    land at the caller's indices."""
+    torch, device, oc, L = env
+    L.lib.zbra_tuning_set_decode_warm(64 << 10, 6, 0)  # the default width limit, any size
+    try:
+        rng = np.random.default_rng(12)
+        specs = [("w31", 5000), ("binary", 70000), ("full", 4097), ("small_signed", 33333), ("narrow", 50000), ("constant", 9000),
+                 ("small_signed", 0), ("time_series", 6143), ("binary", 7), ("w32", 2049), ("small_signed", 123456), ("clustered", 2047)]
+        cols = [column(k, n, seed=40 + i) for i, (k, n) in enumerate(specs)]
+        kinds = [L.ELEM_I64] * len(cols)
+        for n_tags, vals in ((200001, [0, 1]), (70001, [0, 1, 2, 7])):     # u32: width 1-2 is narrow, width 4 is not
+            cols.append(rng.choice(np.array(vals, dtype=np.uint32), n_tags)); kinds.append(L.ELEM_U32)
+        encs = [oc.compress_int_array(c.astype(np.int64)) for c in cols]
+        widths = [e[12] if len(e) > 12 else None for e in encs]
+        assert any(w is not None and w <= 6 for w in widths) and any(w is not None and w > 6 for w in widths)
+        bad = {1: L.ERR_SHORT_PACKED, 4: L.ERR_TRUNCATED}                   # a narrow and a wide array rejected
+        blob, offs, lens = bytearray(), [], []
+        for i, e in enumerate(encs):
+            blob += b"\\xAA" * int(rng.integers(0, 5))
+            offs.append(len(blob))
+            if bad.get(i) == L.ERR_TRUNCATED:
+                cut = bytearray(e[:len(e) - 40]); cut[8:12] = (len(cut) - 12).to_bytes(4, "little"); e = bytes(cut)
+            blob += e
+            lens.append(len(e) - 1 if bad.get(i) == L.ERR_SHORT_PACKED else len(e))
+        d_blob = _dev_bytes(torch, bytes(blob), 3)
+        outs, items = [], []
+        for i, v in enumerate(cols):
+            o = torch.full((v.size + 2,), -3, dtype=torch.int64 if kinds[i] == L.ELEM_I64 else torch.int32, device="cuda")
+            outs.append(o)
+            items.append((d_blob.data_ptr() + offs[i], lens[i], v.size, o.data_ptr() + o.element_size(), kinds[i]))
+        res = device.new_results(len(items), "cuda")
+        device.decode_batch_dev(device.make_descs(items), res)
+        rs = device.read_results(res)
+        for i, v in enumerate(cols):
+            got = outs[i].cpu().numpy()
+            if i in bad:
+                assert rs[i].status == bad[i] and (got == -3).all(), i
+                continue
+            assert rs[i].status == L.OK and rs[i].out_count == v.size, i
+            if v.size:
+                assert rs[i].width == widths[i], i
+            expect = v if kinds[i] == L.ELEM_I64 else v.view(np.int32)
+            assert np.array_equal(got[1:v.size + 1], expect) and got[0] == -3 and got[-1] == -3, (i, specs[i] if i < len(specs) else "tags")
+    finally:
+        L.lib.zbra_tuning_set_decode_warm(64 << 20, 6, 8 << 20)

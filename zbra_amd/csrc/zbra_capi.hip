@@ -205,43 +205,52 @@ struct WarmPlan {
     uint64_t tiles_per_chunk = 0;
     uint32_t tiles_per_wg = 1;
 };
-static WarmPlan warm_plan_for(const zbra_array_desc *descs, size_t nd, uint64_t ntiles, uint64_t all_bytes) {
+static bool warm_route_available() {
+    return g_warm_bytes && decode_config().tile == 2048 && !decode_config().direct;
+}
+// Does this array belong on the warm-up route?  Bits per value as the frame's length says them: exact for
+// a well-formed E (a wrong guess costs time, nothing else).  u32 outputs are half as wide: the same packed
+// bytes buy half the output, so half the width pays.  Arrays too short to tell go either way (`dflt`).
+static bool warm_narrow(const zbra_array_desc &d, bool dflt) {
+    if (d.count < 8 || d.len <= 13) return dflt;
+    return (d.len - 13) * 8 / d.count * (d.kind == ZBRA_ELEM_U32 ? 2 : 1) <= g_warm_bits;
+}
+// Chunking of `ntiles` tiles that hold `bytes` encoded bytes.
+static WarmPlan warm_plan_of(uint64_t ntiles, uint64_t bytes) {
     WarmPlan wp;
-    if (!g_warm_bytes || !ntiles || all_bytes < g_warm_min_bytes || decode_config().tile != 2048 || decode_config().direct) return wp;
-    for (size_t i = 0; i < nd; i++) {
-        const zbra_array_desc &d = descs[i];
-        if (d.count < 8 || d.len <= 13) continue;  // too short to matter (or to tell)
-        // bits per value as the frame's length says them: exact for a well-formed E (a wrong guess costs time, nothing else)
-        // u32 outputs are half as wide: the same packed bytes buy half the output, so half the width pays
-        const uint64_t bits = (d.len - 13) * 8 / d.count * (d.kind == ZBRA_ELEM_U32 ? 2 : 1);
-        if (bits > g_warm_bits) return wp;
-    }
+    if (!ntiles) return wp;
     wp.on = true;
-    const uint64_t tile_bytes = all_bytes / ntiles ? all_bytes / ntiles : 1;
+    const uint64_t tile_bytes = bytes / ntiles ? bytes / ntiles : 1;
     wp.tiles_per_chunk = (g_warm_bytes / tile_bytes) & ~7ull;
     if (wp.tiles_per_chunk < 64) wp.tiles_per_chunk = 64;
     const uint64_t per_wg = 65536 / tile_bytes;
     wp.tiles_per_wg = (uint32_t)(per_wg < 1 ? 1 : per_wg > 256 ? 256 : per_wg);
     return wp;
 }
+static WarmPlan warm_plan_for(const zbra_array_desc *descs, size_t nd, uint64_t ntiles, uint64_t all_bytes) {
+    if (!warm_route_available() || !ntiles || all_bytes < g_warm_min_bytes) return WarmPlan();
+    for (size_t i = 0; i < nd; i++)
+        if (!warm_narrow(descs[i], true)) return WarmPlan();
+    return warm_plan_of(ntiles, all_bytes);
+}
 
 // Tile kernel launches of one submission: all its tiles at once, or chunk by chunk behind the
 // warm-up of each chunk.
 static void launch_decode_submission(hipStream_t stream, const DecodePlan *plans, const uint64_t *ts, const uint32_t *tmap, uint32_t nd,
-                                     uint64_t ntiles, uint32_t order, const WarmPlan &wp) {
+                                     uint64_t first, uint64_t ntiles, uint32_t order, const WarmPlan &wp) {
     DecodeConfig c = decode_config();
     if (!wp.on) {
-        g_decode_fn(c, stream, plans, ts, tmap, nd, 0, ntiles, order);
+        g_decode_fn(c, stream, plans, ts, tmap, nd, first, ntiles, order);
         return;
     }
     c.nt = 2;      // plain loads (they hit what the warm-up left), nontemporal stores
     c.direct = 1;
-    for (uint64_t base = 0; base < ntiles; base += wp.tiles_per_chunk) {
-        const uint64_t n = ntiles - base < wp.tiles_per_chunk ? ntiles - base : wp.tiles_per_chunk;
+    for (uint64_t done = 0; done < ntiles; done += wp.tiles_per_chunk) {
+        const uint64_t n = ntiles - done < wp.tiles_per_chunk ? ntiles - done : wp.tiles_per_chunk;
         const unsigned grid = (unsigned)((n + wp.tiles_per_wg - 1) / wp.tiles_per_wg);
-        hipLaunchKernelGGL((warm_tiles_kernel<2048>), dim3(grid), dim3(256), 0, stream, plans, ts, tmap, nd, base, n, wp.tiles_per_wg,
+        hipLaunchKernelGGL((warm_tiles_kernel<2048>), dim3(grid), dim3(256), 0, stream, plans, ts, tmap, nd, first + done, n, wp.tiles_per_wg,
                            g_warm_bits > 31 ? 31u : g_warm_bits);
-        g_decode_fn(c, stream, plans, ts, tmap, nd, base, n, order);
+        g_decode_fn(c, stream, plans, ts, tmap, nd, first + done, n, order);
     }
 }
 
@@ -309,40 +318,67 @@ static int decode_batch_dev(DeviceCtx *ctx, const zbra_array_desc *descs, size_t
         hipLaunchKernelGGL(plan_decode_one_kernel, dim3(1), dim3(64), 0, stream, descs[0], ntiles, plan, tile_start,
                            d_results);
         if (ntiles)
-            launch_decode_submission(stream, plan, tile_start, nullptr, 1u, ntiles, decode_tile_order(descs[0].len, descs[0].count, 1),
+            launch_decode_submission(stream, plan, tile_start, nullptr, 1u, 0, ntiles, decode_tile_order(descs[0].len, descs[0].count, 1),
                                      warm_plan_for(descs, 1, ntiles, descs[0].len));
         int st = hip_status(hipGetLastError());
         int st2 = ctx->release(s, stream);
         return st != ZBRA_OK ? st : st2;
     }
-    const size_t off_ts = align_up(nd * sizeof(zbra_array_desc), 64);
-    const size_t off_plan = align_up(off_ts + (nd + 1) * sizeof(uint64_t), 64);
-    const size_t off_map = align_up(off_plan + nd * sizeof(DecodePlan), 64);
-    uint64_t ntiles = 0, all_bytes = 0, all_values = 0;
+    // A submission that holds narrow arrays AND others is handed to the device with the narrow ones
+    // first (a stable partition): their tiles then form one range, which takes the warm-up route,
+    // and the other arrays' tiles the range behind it, which takes the default kernel.
+    uint64_t ntiles = 0, all_bytes = 0, all_values = 0, n_tiles = 0, n_bytes = 0, n_values = 0;
+    size_t n_narrow = 0;
+    const bool route = warm_route_available();
     for (size_t i = 0; i < nd; i++) {
-        ntiles += decode_tiles_of(descs[i].count, descs[i].kind);
-        all_bytes += descs[i].len;
-        all_values += descs[i].count;
+        const uint64_t t = decode_tiles_of(descs[i].count, descs[i].kind);
+        ntiles += t; all_bytes += descs[i].len; all_values += descs[i].count;
+        if (route && warm_narrow(descs[i], false)) { n_narrow++; n_tiles += t; n_bytes += descs[i].len; n_values += descs[i].count; }
     }
-    const size_t total = off_map + ntiles * sizeof(uint32_t);  // the map lives on the device only
+    const bool all_narrow = route && warm_plan_for(descs, nd, ntiles, all_bytes).on;
+    const bool mixed = !all_narrow && n_narrow && n_bytes >= g_warm_min_bytes;
+    const size_t off_ts = align_up(nd * sizeof(zbra_array_desc), 64);
+    const size_t off_orig = align_up(off_ts + (nd + 1) * sizeof(uint64_t), 64);       // caller's index of each array (mixed only)
+    const size_t host_bytes = off_orig + (mixed ? nd * sizeof(uint32_t) : 0);
+    const size_t off_plan = align_up(host_bytes, 64);
+    const size_t off_map = align_up(off_plan + nd * sizeof(DecodePlan), 64);
+    const size_t total = off_map + ntiles * sizeof(uint32_t);  // plans and the map live on the device only
     Slot *s;
-    ZBRA_TRY(ctx->acquire(total, &s, off_ts + (nd + 1) * sizeof(uint64_t)));  // plans and the map live on the device only
-    std::memcpy(s->host, descs, nd * sizeof(zbra_array_desc));
+    ZBRA_TRY(ctx->acquire(total, &s, host_bytes));
+    zbra_array_desc *h_descs = (zbra_array_desc *)s->host;
     uint64_t *h_ts = (uint64_t *)((char *)s->host + off_ts);
+    uint32_t *h_orig = (uint32_t *)((char *)s->host + off_orig);
+    if (!mixed) {
+        std::memcpy(h_descs, descs, nd * sizeof(zbra_array_desc));
+    } else {
+        size_t a = 0, b = n_narrow;
+        for (size_t i = 0; i < nd; i++) {
+            const size_t at = warm_narrow(descs[i], false) ? a++ : b++;
+            h_descs[at] = descs[i];
+            h_orig[at] = (uint32_t)i;
+        }
+    }
     uint64_t run = 0;
-    for (size_t i = 0; i < nd; i++) { h_ts[i] = run; run += decode_tiles_of(descs[i].count, descs[i].kind); }
+    for (size_t i = 0; i < nd; i++) { h_ts[i] = run; run += decode_tiles_of(h_descs[i].count, h_descs[i].kind); }
     h_ts[nd] = run;
-    int st = hip_status(hipMemcpyAsync(s->dev, s->host, off_ts + (nd + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, stream));
+    int st = hip_status(hipMemcpyAsync(s->dev, s->host, host_bytes, hipMemcpyHostToDevice, stream));
     if (st == ZBRA_OK) {
         const zbra_array_desc *d_descs = (const zbra_array_desc *)s->dev;
         const uint64_t *d_ts = (const uint64_t *)((char *)s->dev + off_ts);
+        const uint32_t *d_orig = mixed ? (const uint32_t *)((char *)s->dev + off_orig) : nullptr;
         DecodePlan *d_plans = (DecodePlan *)((char *)s->dev + off_plan);
         uint32_t *d_map = (uint32_t *)((char *)s->dev + off_map);
         hipLaunchKernelGGL(plan_decode_batch_kernel, dim3((unsigned)nd), dim3(256), 0, stream, d_descs, (uint32_t)nd, d_ts,
-                           d_plans, d_map, d_results);
-        if (ntiles)
-            launch_decode_submission(stream, d_plans, d_ts, d_map, (uint32_t)nd, ntiles, decode_tile_order(all_bytes, all_values, nd),
-                                     warm_plan_for(descs, nd, ntiles, all_bytes));
+                           d_plans, d_map, d_results, d_orig);
+        if (ntiles && !mixed) {
+            launch_decode_submission(stream, d_plans, d_ts, d_map, (uint32_t)nd, 0, ntiles, decode_tile_order(all_bytes, all_values, nd),
+                                     all_narrow ? warm_plan_of(ntiles, all_bytes) : WarmPlan());
+        } else if (ntiles) {
+            launch_decode_submission(stream, d_plans, d_ts, d_map, (uint32_t)nd, 0, n_tiles, decode_tile_order(n_bytes, n_values, n_narrow),
+                                     warm_plan_of(n_tiles, n_bytes));
+            launch_decode_submission(stream, d_plans, d_ts, d_map, (uint32_t)nd, n_tiles, ntiles - n_tiles,
+                                     decode_tile_order(all_bytes - n_bytes, all_values - n_values, nd - n_narrow), WarmPlan());
+        }
         st = hip_status(hipGetLastError());
     }
     int st2 = ctx->release(s, stream);

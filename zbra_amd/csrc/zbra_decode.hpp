@@ -55,13 +55,15 @@ __device__ __forceinline__ void plan_one(const zbra_array_desc &d, DecodePlan *p
 // One workgroup per array: lane 0 parses the header, then the workgroup writes the array's index
 // into its slice of the tile -> array table, so that a decode workgroup finds its array with one
 // load instead of a binary search over tile_start (ten dependent loads for a thousand arrays).
+// `orig` (may be null): the descriptors were handed over in another order than the caller's
+// (narrow arrays first, see the host); orig[a] is where the caller expects array a's result words.
 __global__ __launch_bounds__(256) void plan_decode_batch_kernel(const zbra_array_desc *__restrict__ descs, uint32_t nd,
                                                                 const uint64_t *__restrict__ tile_start,
                                                                 DecodePlan *__restrict__ plans, uint32_t *__restrict__ tile_map,
-                                                                zbra_dev_result *results) {
+                                                                zbra_dev_result *results, const uint32_t *__restrict__ orig) {
     const uint32_t a = blockIdx.x;
     if (a >= nd) return;
-    if (threadIdx.x == 0) plan_one(descs[a], plans + a, results ? results + a : nullptr);
+    if (threadIdx.x == 0) plan_one(descs[a], plans + a, results ? results + (orig ? orig[a] : a) : nullptr);
     const uint64_t t0 = tile_start[a], t1 = tile_start[a + 1];
     for (uint64_t t = t0 + threadIdx.x; t < t1; t += blockDim.x) tile_map[t] = a;
 }
