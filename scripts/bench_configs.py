@@ -20,7 +20,8 @@ sys.path.insert(0, ROOT)
 
 def timed(fn, reps):
     import torch
-    fn()
+    for _ in range(max(3, reps)):  # the clocks drop while the host checks results: bring them back before timing
+        fn()
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()

@@ -79,13 +79,15 @@ def main():
     assert all(r.status == 0 for r in rs)
     widths = sorted(set(r.width for r in rs))
     assert np.array_equal(outs[3].cpu().numpy(), blocks[0].table.column.fields[3][1].values)
+    for _ in range(30):  # the clocks drop while the host compares results: bring them back before timing
+        device.decode_batch_dev(descs, res)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
-    for _ in range(10):
+    for _ in range(20):
         device.decode_batch_dev(descs, res)
     e1.record()
     torch.cuda.synchronize()
-    k_ms = e0.elapsed_time(e1) / 10
+    k_ms = e0.elapsed_time(e1) / 20
     enc_bytes = sum(arrays[k].len for k in range(na))
     del outs, d_img
     # (ii) host image -> host values
