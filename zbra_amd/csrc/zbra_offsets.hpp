@@ -60,6 +60,32 @@ __device__ __forceinline__ void offsets_values(const DecodePlan &p, uint64_t v0,
     }
 }
 
+// The same for widths up to OFF_DIRECT_MAX_W without the LDS image: the lane's four values lie inside
+// the 64 bits that start at its first value, which three dwords hold; the lane loads them itself
+// (plain loads: neighbouring lanes read overlapping dwords, and the sums pass has left the packed
+// bytes in the caches).  Dwords past the last payload byte are never touched.
+constexpr uint32_t OFF_DIRECT_MAX_W = 16;
+__device__ __forceinline__ void offsets_values_direct(const DecodePlan &p, uint64_t v0, uint32_t nv, uint32_t j, uint64_t (&v)[OFF_PER]) {
+    const uint32_t w = p.width;
+#pragma unroll
+    for (int k = 0; k < OFF_PER; k++) v[k] = 0;
+    if (j >= nv) return;
+    const uintptr_t P = (uintptr_t)p.payload;
+    const uint64_t bit = (v0 + j) * w;                       // of the lane's first value, from the payload's first byte
+    const uintptr_t A = P + (bit >> 3);                      // the byte that holds it
+    const uintptr_t A4 = A & ~(uintptr_t)3;
+    const uint32_t s = (uint32_t)(A - A4) * 8u + (uint32_t)(bit & 7u);   // 0..31
+    const uintptr_t last = (P + p.avail - 1) & ~(uintptr_t)3;             // dword of the last payload byte
+    const uint32_t d0 = *gptr<uint32_t>(A4);
+    const uint32_t d1 = A4 + 4 <= last ? *gptr<uint32_t>(A4 + 4) : 0u;
+    const uint32_t d2 = A4 + 8 <= last ? *gptr<uint32_t>(A4 + 8) : 0u;
+    const uint64_t x = ((uint64_t)__builtin_amdgcn_alignbit(d2, d1, s) << 32) | __builtin_amdgcn_alignbit(d1, d0, s);  // the 64 bits that start at the value
+    const uint32_t mask = (1u << w) - 1u;
+#pragma unroll
+    for (int k = 0; k < OFF_PER; k++)
+        if (j + k < nv) v[k] = (uint64_t)(p.midpoint + (int64_t)zigzag_decode32((uint32_t)(x >> (k * w)) & mask));
+}
+
 __device__ __forceinline__ uint64_t wave_sum_u64(uint64_t v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
@@ -190,10 +216,17 @@ __global__ __launch_bounds__(OFF_THREADS) void offsets_write_kernel(const Decode
     if (v0 >= p.count) return;  // uniform
     const uint64_t left = p.count - v0;
     const uint32_t nv = left < (uint64_t)OFF_TILE ? (uint32_t)left : (uint32_t)OFF_TILE;
-    const uint32_t base_bits = offsets_stage(p, v0, nv, lds);
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6, j = threadIdx.x * OFF_PER;
     uint64_t v[OFF_PER];
-    offsets_values(p, v0, nv, base_bits, lds, j, v);
+#ifndef ZBRA_OFF_NO_DIRECT
+    if (p.width - 1u < OFF_DIRECT_MAX_W) {  // uniform
+        offsets_values_direct(p, v0, nv, j, v);
+    } else
+#endif
+    {
+        const uint32_t base_bits = offsets_stage(p, v0, nv, lds);
+        offsets_values(p, v0, nv, base_bits, lds, j, v);
+    }
     const uint64_t mine = (v[0] + v[1]) + (v[2] + v[3]);
     uint64_t inc = mine;  // inclusive scan of the lanes' totals across the wave
 #pragma unroll
