@@ -82,8 +82,6 @@ struct EncodeJob {
     uint64_t *small;     // GATHER_CAP keys gathered by a level for the finishing workgroup (long arrays only)
     uint32_t small_n;
     uint32_t pending;    // 1 = on the list of the many-workgroup levels
-    uint32_t dense_bracket;  // the sample says that a large share of the values lies inside a bracket of few keys (see MICRO_KEYS)
-    uint32_t pad_;
     // smallest / largest key among those whose next digit level L counted (all equal: a run of one
     // value, which needs no further digit)
     unsigned long long match_min[3], match_max[3];
@@ -465,11 +463,19 @@ __global__ __launch_bounds__(SAMPLE_THREADS) void enc_sample_kernel(EncodeJob *_
     inside = 0;
     for (uint32_t w = 0; w < SAMPLE_THREADS / 64; w++) inside += sh.wave_sum[0][w];
     job.min_b = got[2]; job.max_b = got[3];  // of the sample: where the bracket pass's minimum and maximum start
-    job.lo_b = lo_b;
-    job.hi_b = hi_b;
-    // A bracket of few keys that holds a large share of the values (more than a tenth of them per
-    // key) is counted in per-lane columns; a sparse one goes to the shared histogram like any other.
-    job.dense_bracket = hi_b - lo_b < (uint64_t)MICRO_KEYS && (uint64_t)inside * 10 > (uint64_t)sample * (hi_b - lo_b + 1);
+    // A bracket of 3 to MICRO_KEYS keys is counted in per-lane columns by the bracket pass, which pays
+    // when it holds a large share of the values (more than a tenth of them per key: lanes would queue
+    // on the few bins of a shared histogram) and costs twice the pass when it does not (32-64 equally
+    // likely values: 7 % of them inside).  A sparse one is therefore widened to MICRO_KEYS + 1 keys, which
+    // sends it to the shared histogram like any other narrow bracket; a wider bracket is as valid.
+    uint64_t lo_w = lo_b, hi_w = hi_b;
+    const uint64_t span = hi_b - lo_b;
+    if (span >= 2 && span < (uint64_t)MICRO_KEYS && (uint64_t)inside * 10 <= (uint64_t)sample * (span + 1)) {
+        const uint64_t add = (uint64_t)MICRO_KEYS - span;
+        if (hi_w <= ~0ull - add) hi_w += add; else lo_w -= add;  // hi_b near the top of the range leaves room below (span < 8 <= lo_b)
+    }
+    job.lo_b = lo_w;
+    job.hi_b = hi_w;
     job.key_base = job.lo_b;  // keys of a bracket select: (v ^ SIGN) - lo_b
     job.key_bits = bit_length64(job.hi_b - job.lo_b);
     job.passes = (job.key_bits + DIGIT_BITS - 1) / DIGIT_BITS;
@@ -585,8 +591,7 @@ __global__ __launch_bounds__(THREADS, ZBRA_BRACKET_WAVES) void enc_bracket_kerne
         // a histogram-mode array with a tiny bracket counts in per-lane columns (see MICRO_KEYS)
         const uint64_t bspan = job.hi_b - job.lo_b;
         const uint32_t mode = job.mode != SEL_BRACKET_HIST || bspan >= (uint64_t)MICRO_KEYS ? job.mode
-                              : bspan == 0 ? SEL_BRACKET_ONE : bspan == 1 ? SEL_BRACKET_TWO
-                              : job.dense_bracket ? SEL_BRACKET_MICRO : (uint32_t)SEL_BRACKET_HIST;
+                              : bspan == 0 ? SEL_BRACKET_ONE : bspan == 1 ? SEL_BRACKET_TWO : SEL_BRACKET_MICRO;
         const void *values = job.values;
         const uint32_t kind = job.kind;
         const uint64_t n = job.n, seg_cap = job.seg_cap;
