@@ -336,7 +336,8 @@ static int decode_batch_dev(DeviceCtx *ctx, const zbra_array_desc *descs, size_t
         if (route && warm_narrow(descs[i], false)) { n_narrow++; n_tiles += t; n_bytes += descs[i].len; n_values += descs[i].count; }
     }
     const bool all_narrow = route && warm_plan_for(descs, nd, ntiles, all_bytes).on;
-    const bool mixed = !all_narrow && n_narrow && n_bytes >= g_warm_min_bytes;
+    // worth its two extra launches only when the narrow arrays are a fair share of the work (a quarter of the tiles)
+    const bool mixed = !all_narrow && n_narrow && n_bytes >= g_warm_min_bytes && n_tiles * 4 >= ntiles;
     const size_t off_ts = align_up(nd * sizeof(zbra_array_desc), 64);
     const size_t off_orig = align_up(off_ts + (nd + 1) * sizeof(uint64_t), 64);       // caller's index of each array (mixed only)
     const size_t host_bytes = off_orig + (mixed ? nd * sizeof(uint32_t) : 0);
