@@ -79,6 +79,10 @@ assert all(np.array_equal(d_h[i0:i0 + STEP], v_h[i0:i0 + STEP]) for i0 in range(
 print(json.dumps({"check": "host-pointer int64 encode + decode", "n": N, "ok": True}), flush=True)
 del v_h, e_h, d_h
 
+# 1c. a narrow column (width 3 or 4): its decode takes the warm-up route, here in two dozen chunks
+roundtrip("int64 encode + decode, narrow (warm-up route)", torch.int64, lambda i: (i * 2654435761) % 5 + (i >> 31) - 2, (3, 4))
+torch.cuda.empty_cache()
+
 # 2. the same bytes as lengths: offsets[i + 1] = offsets[i] + v[i]
 offs = torch.empty(N + 1, dtype=torch.int64, device=dev)
 device.decode_offsets_dev(enc, N, offs, None, length=elen)
