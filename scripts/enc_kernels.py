@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Encodes one device-resident column a few times (run it under rocprofv3 --kernel-trace --stats to
-see the per-kernel times).  Usage: enc_kernels.py narrow|wide|time|w40|full [rows_log2]"""
+see the per-kernel times).  Usage: enc_kernels.py narrow|wide|time|w40|heavy|bool|full [rows_log2]"""
 import os
 import sys
 
@@ -20,6 +20,11 @@ elif kind == "wide":
     v = torch.randint(-(1 << 24), 1 << 24, (n,), dtype=torch.int64, device=dev, generator=g)
 elif kind == "time":  # sorted: one timestamp a second
     v = 1_640_995_200_000 + torch.arange(n, dtype=torch.int64, device=dev) * 1000
+elif kind == "heavy":  # 45/3/3/49 %: a dense bracket of three keys
+    u = torch.randint(0, 100, (n,), dtype=torch.int64, device=dev, generator=g)
+    v = torch.where(u < 45, 0, torch.where(u < 48, 1, torch.where(u < 51, 2, 3)))
+elif kind == "bool":
+    v = torch.randint(0, 2, (n,), dtype=torch.int64, device=dev, generator=g)
 elif kind == "w40":
     v = torch.randint(-(1 << 38), 1 << 38, (n,), dtype=torch.int64, device=dev, generator=g)
 else:
