@@ -119,7 +119,7 @@ enum SelectMode : uint32_t {
     SEL_DONE = 3             // midpoint and width already known (small array sorted whole, constant, ...)
 };
 
-constexpr uint32_t MICRO_KEYS = 8;     // brackets of fewer keys than this may be counted in per-lane columns (see SEL_BRACKET_MICRO)
+constexpr uint32_t MICRO_KEYS = 8;     // brackets of fewer keys than this are counted in per-lane columns (see SEL_BRACKET_MICRO)
 constexpr int SAMPLE = 4096;          // sample keys of an array (four per lane of the sampling workgroup)
 constexpr int SAMPLE_THREADS = 1024;  // lanes of the sampling workgroup
 constexpr int SAMPLE_MARGIN = 128;    // sample ranks either side: 4 sigma, sigma = sqrt(SAMPLE)/2 = 32
@@ -450,32 +450,10 @@ __global__ __launch_bounds__(SAMPLE_THREADS) void enc_sample_kernel(EncodeJob *_
     const bool has_lo = r >= (uint64_t)margin, has_hi = r + margin < (uint64_t)sample;
     select_two_ranks(key, nvalid, has_lo ? (uint32_t)(r - margin) : 0u, has_hi ? (uint32_t)(r + margin) : sample - 1, &sh, got);
     const uint64_t lo_b = has_lo ? got[0] : 0, hi_b = has_hi ? got[1] : ~0ull;
-    // how many of the sample's keys lie inside the bracket (ties at its ends make that more than 2 * margin)
-    uint32_t inside = 0;
-#pragma unroll
-    for (int i = 0; i < SAMPLE_PER; i++) inside += (uint32_t)i < nvalid && key[i] >= lo_b && key[i] <= hi_b;
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) inside += __shfl_xor(inside, o);
-    __syncthreads();  // select_two_ranks is done with wave_sum
-    if ((threadIdx.x & 63u) == 0) sh.wave_sum[0][threadIdx.x >> 6] = inside;
-    __syncthreads();
     if (threadIdx.x != 0) return;
-    inside = 0;
-    for (uint32_t w = 0; w < SAMPLE_THREADS / 64; w++) inside += sh.wave_sum[0][w];
     job.min_b = got[2]; job.max_b = got[3];  // of the sample: where the bracket pass's minimum and maximum start
-    // A bracket of 3 to MICRO_KEYS keys is counted in per-lane columns by the bracket pass, which pays
-    // when it holds a large share of the values (more than a tenth of them per key: lanes would queue
-    // on the few bins of a shared histogram) and costs twice the pass when it does not (32-64 equally
-    // likely values: 7 % of them inside).  A sparse one is therefore widened to MICRO_KEYS + 1 keys, which
-    // sends it to the shared histogram like any other narrow bracket; a wider bracket is as valid.
-    uint64_t lo_w = lo_b, hi_w = hi_b;
-    const uint64_t span = hi_b - lo_b;
-    if (span >= 2 && span < (uint64_t)MICRO_KEYS && (uint64_t)inside * 10 <= (uint64_t)sample * (span + 1)) {
-        const uint64_t add = (uint64_t)MICRO_KEYS - span;
-        if (hi_w <= ~0ull - add) hi_w += add; else lo_w -= add;  // hi_b near the top of the range leaves room below (span < 8 <= lo_b)
-    }
-    job.lo_b = lo_w;
-    job.hi_b = hi_w;
+    job.lo_b = lo_b;
+    job.hi_b = hi_b;
     job.key_base = job.lo_b;  // keys of a bracket select: (v ^ SIGN) - lo_b
     job.key_bits = bit_length64(job.hi_b - job.lo_b);
     job.passes = (job.key_bits + DIGIT_BITS - 1) / DIGIT_BITS;
@@ -495,8 +473,8 @@ struct BracketAcc {
 // every lane's atomic on the same few addresses, which serialise.  Each lane counts by itself
 // instead: in eight 8-bit fields of one register pair while it reads, emptied every MICRO_TILES
 // tiles into its own column of the pool (key k of lane t at lh[k * THREADS + t]: no two lanes ever
-// meet), and the columns are summed when the run ends.  (A read-modify-write of the column per
-// value, and a ballot per key and value, both doubled the time of the pass.)
+// meet), and the columns are summed when the run ends: per wave, then per workgroup in LDS, so
+// that each workgroup sends ONE atomic per key to the array's histogram.
 static_assert(MICRO_KEYS * THREADS + MICRO_KEYS <= (uint32_t)BINS, "the private columns and their sums live in the histogram pool");
 static_assert(MICRO_KEYS == 8, "one byte per key in a 64-bit register pair");
 constexpr uint32_t MICRO_TILES = 255 / (2 * PAIRS);  // tiles a lane's 8-bit counts hold: 2 * PAIRS values per tile
@@ -1564,7 +1542,25 @@ __device__ __forceinline__ void pack_tile_narrow(const EncodeJob &job, uint64_t 
     const uint32_t ndw = (off4 + nbytes + 3u) >> 2;
     const uint64_t inv = (0x100000000ull + w - 1) / w;
     for (uint32_t d = tid; d < ndw; d += THREADS) {
-        const uint32_t v = stream_dword(zz, (int32_t)(d * 32u) - (int32_t)(off4 * 8u), w, inv);
+        const int32_t lo = (int32_t)(d * 32u) - (int32_t)(off4 * 8u);
+        uint32_t v;
+        if (w <= 2 && lo >= 0 && (uint32_t)lo + 32u <= (uint32_t)TILE * w) {
+            // One- and two-bit values (booleans, constant columns): the dword's 32 / w values lie wholly
+            // inside the tile and start at a multiple of four (lo is a multiple of 8), so they are read
+            // sixteen bytes at a time instead of one value per trip: few lanes have a dword here, and the
+            // rest of the workgroup waits for them.
+            const uint4 *z4 = (const uint4 *)(zz + ((uint32_t)lo >> (w - 1)));
+            v = 0;
+            if (w == 1) {
+#pragma unroll
+                for (int q = 0; q < 8; q++) { const uint4 z = z4[q]; v |= (z.x | z.y << 1 | z.z << 2 | z.w << 3) << (4 * q); }
+            } else {
+#pragma unroll
+                for (int q = 0; q < 4; q++) { const uint4 z = z4[q]; v |= (z.x | z.y << 2 | z.z << 4 | z.w << 6) << (8 * q); }
+            }
+        } else {
+            v = stream_dword(zz, lo, w, inv);
+        }
         const uintptr_t addr = G4 + (uintptr_t)d * 4;
         if (addr >= G && addr + 4 <= Gend) {
             __builtin_nontemporal_store(v, gptr_mut<uint32_t>(addr));
