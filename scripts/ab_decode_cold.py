@@ -21,6 +21,7 @@ def main():
     ap.add_argument("--arrays", type=int, default=1, help="cut the column into this many equal arrays, decoded as one batch")
     ap.add_argument("--tags", action="store_true", help="u32 tag column instead of an int64 column")
     ap.add_argument("--amp-bits", type=int, default=0, help="int64 column of this amplitude (the width sweep's generator); 0 = the headline column")
+    ap.add_argument("--ones-percent", type=int, default=-1, help="boolean int64 column with this share of ones (100: a constant column): width 1 above 50, width 2 below")
     args = ap.parse_args()
     import torch
 
@@ -29,6 +30,8 @@ def main():
     n = 1 << args.rows_log2
     if args.tags:
         values, _ = workloads.enum_block(0, n, dev)
+    elif args.ones_percent >= 0:
+        values = (workloads.umod(workloads.sm(0xABCDEF, torch.arange(n, dtype=torch.int64, device=dev)), 100) < args.ones_percent).to(torch.int64)
     elif args.amp_bits:
         rnd = workloads.sm(0xABCDEF, torch.arange(n, dtype=torch.int64, device=dev))
         values = rnd if args.amp_bits == 64 else (rnd & ((1 << args.amp_bits) - 1)) - (1 << (args.amp_bits - 1)) + 1_000_000_007

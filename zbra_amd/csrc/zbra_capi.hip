@@ -504,7 +504,9 @@ static int encode_batch_dev(DeviceCtx *ctx, const EncodeItem *items, size_t nd, 
     };
     uint32_t n_list = 0, n_big = 0;
     size_t scratch_bytes = 0;
+    bool may_need_or = false;  // u32 values span less than 2^63: their width follows from minimum, maximum and midpoint
     for (size_t i = 0; i < nd; i++) {
+        may_need_or = may_need_or || (items[i].n && items[i].kind != ZBRA_ELEM_U32);
         n_list += listed(items[i]) ? 1u : 0u;
         n_big += is_long(items[i]) ? 1u : 0u;
         scratch_bytes += seg_cap_of(items[i]) * CAND_SEGS * sizeof(int64_t);
@@ -611,7 +613,7 @@ static int encode_batch_dev(DeviceCtx *ctx, const EncodeItem *items, size_t nd, 
                 hipLaunchKernelGGL(enc_level_kernel, dim3(gh), dim3(THREADS), 0, stream, d_jobs, d_pend, L, sparse_tiles);
             if (n_list)
                 hipLaunchKernelGGL(enc_finish_select_kernel, dim3(n_list), dim3(THREADS), 0, stream, d_jobs, d_list, n_list);
-            if (mode == ENCODE_FULL) {
+            if (mode == ENCODE_FULL && may_need_or) {
                 // Few arrays of a batch need this pass (a span of 2^63 or more whose extremes do not
                 // already take 64 bits), and a contiguous run per resident workgroup would leave
                 // each of them to the two or three workgroups whose runs it crosses: short runs of
