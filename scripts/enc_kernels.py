@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Encodes one device-resident column a few times (run it under rocprofv3 --kernel-trace --stats to
-see the per-kernel times).  Usage: enc_kernels.py narrow|wide|time|w40|heavy|bool|full [rows_log2]"""
+see the per-kernel times).  Usage: enc_kernels.py narrow|wide|time|w40|heavy|bool|ends|full [rows_log2]"""
 import os
 import sys
 
@@ -23,6 +23,10 @@ elif kind == "time":  # sorted: one timestamp a second
 elif kind == "heavy":  # 45/3/3/49 %: a dense bracket of three keys
     u = torch.randint(0, 100, (n,), dtype=torch.int64, device=dev, generator=g)
     v = torch.where(u < 45, 0, torch.where(u < 48, 1, torch.where(u < 51, 2, 3)))
+elif kind == "ends":  # i64::MIN and i64::MAX among small values: the span wraps, the width comes from the OR pass
+    v = torch.randint(0, 1000, (n,), dtype=torch.int64, device=dev, generator=g)
+    v[n // 3] = -(1 << 63)
+    v[2 * n // 3] = (1 << 63) - 1
 elif kind == "bool":
     v = torch.randint(0, 2, (n,), dtype=torch.int64, device=dev, generator=g)
 elif kind == "w40":

@@ -1382,7 +1382,10 @@ __global__ __launch_bounds__(THREADS) void enc_or_kernel(EncodeJob *__restrict__
             for (int e = 0; e < 2 * PAIRS; ++e) acc |= to_stream(job, x[e], mid);
         }
         acc = wave_or_u64(acc);
-        if ((threadIdx.x & 63) == 0 && acc) atomicOr((unsigned long long *)&jobs[a].or_bits, (unsigned long long)acc);
+        // every wave would queue on this one word: look first (the bits settle after a few waves, and
+        // a stale look only costs an atomic that changes nothing)
+        if ((threadIdx.x & 63) == 0 && (acc & ~__hip_atomic_load(&jobs[a].or_bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)))
+            atomicOr((unsigned long long *)&jobs[a].or_bits, (unsigned long long)acc);
     });
 }
 
