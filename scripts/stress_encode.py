@@ -57,6 +57,12 @@ def make_array(torch, g, dev, kind, n):
     if kind == "cluster_in_wide":              # a dense cluster of different values at the median of wide data
         v = torch.where(rnd(0, 2) == 0, -rnd(1 << 40, 1 << 62), rnd(1 << 40, 1 << 62))
         return torch.where(rnd(0, 100) < 4, 500_000_000 + rnd(0, 5000), v)
+    if kind == "heavy_ends":                   # a dense bracket of three keys: 45/3/3/49 %
+        u = rnd(0, 100)
+        return torch.where(u < 45, 0, torch.where(u < 48, 1, torch.where(u < 51, 2, 3)))
+    if kind == "few_tags":                     # a bracket of up to eight keys with a rare key at the median
+        u = rnd(0, 100)
+        return torch.where(u < 40, 7, torch.where(u < 47, 8 + u % 4, torch.where(u < 53, 12 + u % 3, 15)))
     if kind == "doubles":                      # f64 bit patterns of a normal-ish spread around zero
         x = (torch.rand(n, device=dev, generator=g, dtype=torch.float64) - 0.5) * 1e6
         return x.view(torch.int64)
@@ -64,7 +70,7 @@ def make_array(torch, g, dev, kind, n):
 
 
 KINDS = ["constant", "two", "two_far", "narrow", "wide", "w40", "full", "sorted", "reversed", "sawtooth", "median_run",
-         "outliers", "skewed", "full64", "three_far", "popular_in_wide", "cluster_in_wide", "doubles"]
+         "outliers", "skewed", "full64", "three_far", "popular_in_wide", "cluster_in_wide", "heavy_ends", "few_tags", "doubles"]
 
 
 def expected(torch, v):
