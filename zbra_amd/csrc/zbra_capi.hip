@@ -585,7 +585,11 @@ static int encode_batch_dev(DeviceCtx *ctx, const EncodeItem *items, size_t nd, 
         // with 1024 workgroups, 1754 with 2048, 1649 with 4096, 1643 with 8192, 1688 with 16384,
         // 2122 with 65536.
         static const unsigned bracket_grid = [] { const char *e = getenv("ZBRA_HIP_BRACKET_GRID"); return e ? (unsigned)atol(e) : 0u; }();
-        const unsigned gs = grid_for(ntiles, bracket_grid ? bracket_grid : nd == 1 ? STREAM_GRID_CAP / 2 : STREAM_GRID_CAP * 4);
+        // A run's end costs a merge of the workgroup's histogram into the array's (thousands of
+        // atomics), so a batch's runs are kept at 32 tiles or more: 2^26 rows as 4 to 1024 arrays
+        // took 183-208 us in this pass with 8192 workgroups of 4 tiles each, 100-114 us with 1024.
+        const uint64_t batch_grid = ntiles / 32 < STREAM_GRID_CAP / 2 ? STREAM_GRID_CAP / 2 : ntiles / 32 < STREAM_GRID_CAP * 4 ? ntiles / 32 : STREAM_GRID_CAP * 4;
+        const unsigned gs = grid_for(ntiles, bracket_grid ? bracket_grid : nd == 1 ? STREAM_GRID_CAP / 2 : (unsigned)batch_grid);
         const unsigned ga = (unsigned)((nd + 255) / 256);
         // workgroups of a many-workgroup select level, dealt to the arrays it finds pending
         static const unsigned level_grid = [] { const char *e = getenv("ZBRA_HIP_LEVEL_GRID"); return e ? (unsigned)atol(e) : 0u; }();
