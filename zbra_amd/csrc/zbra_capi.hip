@@ -629,7 +629,7 @@ static int encode_batch_dev(DeviceCtx *ctx, const EncodeItem *items, size_t nd, 
         }
         if (mode == ENCODE_FULL) {
             if (frames)
-                hipLaunchKernelGGL(enc_frame_layout_kernel, dim3(1), dim3(256), 0, stream, d_jobs, (uint32_t)nd, frames->out,
+                hipLaunchKernelGGL(enc_frame_layout_kernel, dim3(1), dim3(nd > 1024 ? 1024 : 256), 0, stream, d_jobs, (uint32_t)nd, frames->out,
                                    frames->cap, frames->offsets);
             hipLaunchKernelGGL(enc_finalize_kernel, dim3(ga), dim3(256), 0, stream, d_jobs, (uint32_t)nd, d_results);
             if (ntiles) {
