@@ -411,9 +411,13 @@ __global__ __launch_bounds__(SAMPLE_THREADS) void enc_sample_kernel(EncodeJob *_
     const bool whole = n <= (uint64_t)SAMPLE;
     // An array too short for a candidate list (seg_cap == 0) only asks the sample whether its
     // bracket is narrow enough for the histogram route: a quarter of the keys answers that.
-    const uint32_t sample = whole ? (uint32_t)n : job.seg_cap ? (uint32_t)SAMPLE : (uint32_t)SAMPLE / 4;
+    // The sample of a longer array is a power of two, and counts stay below 2^32 (the frame's u32):
+    // strides, offsets and the expected rank below need no 128-bit product and one 64-bit division.
+    static_assert((SAMPLE & (SAMPLE - 1)) == 0 && SAMPLE >= 4, "power-of-two sample");
+    const uint32_t sample_log2 = (uint32_t)__builtin_ctz((unsigned)SAMPLE) - (job.seg_cap ? 0u : 2u);
+    const uint32_t sample = whole ? (uint32_t)n : 1u << sample_log2;
     const uint32_t margin = job.seg_cap ? (uint32_t)SAMPLE_MARGIN : (uint32_t)SAMPLE_MARGIN / 2;  // 4 sigma of sqrt(sample) / 2
-    const uint64_t stride = whole ? 1 : n / sample;
+    const uint64_t stride = whole ? 1 : n >> sample_log2;  // below 2^22
     uint64_t key[SAMPLE_PER];
     uint32_t nvalid = 0;  // this lane holds keys j = tid + i * SAMPLE_THREADS, i < nvalid
 #pragma unroll
@@ -424,10 +428,11 @@ __global__ __launch_bounds__(SAMPLE_THREADS) void enc_sample_kernel(EncodeJob *_
             uint64_t at = j;
             if (!whole) {
                 // one value from each of `sample` equal strides, at a hashed offset inside it, so that
-                // periodic data does not alias with the sampling step
+                // periodic data does not alias with the sampling step; the offset is the hash's upper
+                // half scaled to the stride (a multiply and a shift: no division)
                 uint64_t h = (j + 1) * 0x9E3779B97F4A7C15ull;
                 h ^= h >> 29; h *= 0xBF58476D1CE4E5B9ull; h ^= h >> 32;
-                at = (uint64_t)j * stride + h % stride;
+                at = (uint64_t)j * stride + (((h >> 32) * stride) >> 32);
             }
             key[i] = (uint64_t)load_value(job, at) ^ SIGN;
             nvalid = (uint32_t)i + 1;
@@ -446,7 +451,7 @@ __global__ __launch_bounds__(SAMPLE_THREADS) void enc_sample_kernel(EncodeJob *_
         set_midpoint(job, (int64_t)(got[0] ^ SIGN), (int64_t)(got[1] ^ SIGN), even);
         return;
     }
-    const uint64_t r = (uint64_t)(((unsigned __int128)k * sample) / n);  // expected sample rank of a
+    const uint64_t r = (k << sample_log2) / n;  // expected sample rank of a (k < 2^31)
     const bool has_lo = r >= (uint64_t)margin, has_hi = r + margin < (uint64_t)sample;
     select_two_ranks(key, nvalid, has_lo ? (uint32_t)(r - margin) : 0u, has_hi ? (uint32_t)(r + margin) : sample - 1, &sh, got);
     const uint64_t lo_b = has_lo ? got[0] : 0, hi_b = has_hi ? got[1] : ~0ull;
