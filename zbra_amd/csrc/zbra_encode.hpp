@@ -475,14 +475,12 @@ struct BracketAcc {
     uint32_t first = 0;  // two-key bracket: values equal to its lower key
 };
 // Brackets of at most MICRO_KEYS keys (enum tags, booleans): a shared LDS histogram would take
-// every lane's atomic on the same few addresses, which serialise.  Each lane counts by itself
-// instead: in eight 8-bit fields of one register pair while it reads, emptied every MICRO_TILES
-// tiles into its own column of the pool (key k of lane t at lh[k * THREADS + t]: no two lanes ever
-// meet), and the columns are summed when the run ends: per wave, then per workgroup in LDS, so
-// that each workgroup sends ONE atomic per key to the array's histogram.
+// every lane's atomic on the same few addresses, which serialise.  Each lane counts in its own
+// column of the pool instead (key k of lane t at lh[k * THREADS + t]: no two lanes ever meet), and
+// the columns are summed when the run ends: per wave, then per workgroup in LDS, so that each
+// workgroup sends ONE atomic per key to the array's histogram (atomics on one word from all over
+// the chip queue behind each other: one per wave made this pass twice as long).
 static_assert(MICRO_KEYS * THREADS + MICRO_KEYS <= (uint32_t)BINS, "the private columns and their sums live in the histogram pool");
-static_assert(MICRO_KEYS == 8, "one byte per key in a 64-bit register pair");
-constexpr uint32_t MICRO_TILES = 255 / (2 * PAIRS);  // tiles a lane's 8-bit counts hold: 2 * PAIRS values per tile
 constexpr uint32_t SEL_BRACKET_MICRO = 100;  // template tag only: a histogram-mode array with a tiny bracket
 // A bracket of ONE key (more than 6 % of the values are the median: a popular tag, a boolean, a
 // default value) needs no histogram at all, its one bin is the count of values inside; a bracket
@@ -500,7 +498,7 @@ constexpr uint32_t SEL_BRACKET_ONE = 101, SEL_BRACKET_TWO = 102;  // template ta
 template <uint32_t MODE, bool WHOLE, int E0, int E1>
 __device__ __forceinline__ void bracket_values(const int64_t (&x)[2 * PAIRS], uint32_t kind, uint64_t v0, uint64_t n, uint64_t lo_b,
                                                uint64_t hi_b, BracketAcc &acc, uint32_t *lh, int64_t *lcand, uint32_t *lcount,
-                                               uint32_t digit_shift = 0, uint32_t *wave_cnt = nullptr, uint64_t *lane_cnt = nullptr) {
+                                               uint32_t digit_shift = 0, uint32_t *wave_cnt = nullptr) {
     // lanes past the end hold a value of the array: harmless here
     uint64_t improves = 0;  // uniform: lanes with a value beyond what they hold
 #pragma unroll
@@ -548,8 +546,7 @@ __device__ __forceinline__ void bracket_values(const int64_t (&x)[2 * PAIRS], ui
             } else if (MODE == SEL_BRACKET_TWO) {
                 acc.first += inside && b == lo_b;
             } else if (MODE == SEL_BRACKET_MICRO) {
-                // one 8-bit count per key in the lane's register pair: no LDS access, no branch
-                *lane_cnt += (uint64_t)inside << (((uint32_t)(b - lo_b) & (MICRO_KEYS - 1)) * 8);
+                if (inside) lh[((uint32_t)(b - lo_b) & (MICRO_KEYS - 1)) * THREADS + threadIdx.x] += 1u;
             } else if (inside) {
                 atomicAdd(&lh[(uint32_t)(b - lo_b)], 1u);
             }
@@ -633,26 +630,6 @@ __global__ __launch_bounds__(THREADS, ZBRA_BRACKET_WAVES) void enc_bracket_kerne
         uint64_t S = 0;
         if (step == 1 && T > 512) S = T % 127 ? 127 : T % 131 ? 131 : T % 137 ? 137 : 139;  // T < 127 * 131 * 137 * 139
         uint64_t q = S ? ((t0 - a_first) * S) % T : t0 - a_first;  // tile of the array, uniform
-        if (mode == SEL_BRACKET_MICRO) {  // a loop of its own: its counting register is live nowhere else
-            uint64_t lane_cnt = 0;
-            uint32_t held = 0;  // tiles counted in lane_cnt, uniform
-            auto empty_counts = [&]() {
-#pragma unroll
-                for (uint32_t k = 0; k < MICRO_KEYS; k++) lh[k * THREADS + threadIdx.x] += (uint32_t)(lane_cnt >> (8 * k)) & 255u;
-                lane_cnt = 0;
-                held = 0;
-            };
-            for (uint64_t t = t0; t < t1; t += step) {
-                const uint64_t v0 = q * TILE;
-                q = S ? (q + S >= T ? q + S - T : q + S) : q + step;
-                int64_t x[2 * PAIRS];
-                load_tile_from(values, kind, v0, n, fill, x);
-                if (v0 + TILE <= n) bracket_values<SEL_BRACKET_MICRO, true, 0, 2 * PAIRS>(x, kind, v0, n, lo_b, hi_b, acc, lh, nullptr, nullptr, 0, nullptr, &lane_cnt);
-                else bracket_values<SEL_BRACKET_MICRO, false, 0, 2 * PAIRS>(x, kind, v0, n, lo_b, hi_b, acc, lh, nullptr, nullptr, 0, nullptr, &lane_cnt);
-                if (++held == MICRO_TILES) empty_counts();
-            }
-            empty_counts();
-        } else
         for (uint64_t t = t0; t < t1; t += step) {
             const uint64_t v0 = q * TILE;
             q = S ? (q + S >= T ? q + S - T : q + S) : q + step;
@@ -664,6 +641,9 @@ __global__ __launch_bounds__(THREADS, ZBRA_BRACKET_WAVES) void enc_bracket_kerne
                 else bracket_values<SEL_BRACKET_HIST, false, 0, 2 * PAIRS>(x, kind, v0, n, lo_b, hi_b, acc, lh, nullptr, nullptr);
             } else if (mode == SEL_FULL) {
                 bracket_values<SEL_FULL, true, 0, 2 * PAIRS>(x, kind, v0, n, lo_b, hi_b, acc, lh, nullptr, nullptr);
+            } else if (mode == SEL_BRACKET_MICRO) {
+                if (whole) bracket_values<SEL_BRACKET_MICRO, true, 0, 2 * PAIRS>(x, kind, v0, n, lo_b, hi_b, acc, lh, nullptr, nullptr);
+                else bracket_values<SEL_BRACKET_MICRO, false, 0, 2 * PAIRS>(x, kind, v0, n, lo_b, hi_b, acc, lh, nullptr, nullptr);
             } else if (mode == SEL_BRACKET_ONE) {
                 if (whole) bracket_values<SEL_BRACKET_ONE, true, 0, 2 * PAIRS>(x, kind, v0, n, lo_b, hi_b, acc, lh, nullptr, nullptr);
                 else bracket_values<SEL_BRACKET_ONE, false, 0, 2 * PAIRS>(x, kind, v0, n, lo_b, hi_b, acc, lh, nullptr, nullptr);
@@ -1551,19 +1531,27 @@ __device__ __forceinline__ void pack_tile_narrow(const EncodeJob &job, uint64_t 
     for (uint32_t d = tid; d < ndw; d += THREADS) {
         const int32_t lo = (int32_t)(d * 32u) - (int32_t)(off4 * 8u);
         uint32_t v;
-        if (w <= 2 && lo >= 0 && (uint32_t)lo + 32u <= (uint32_t)TILE * w) {
-            // One- and two-bit values (booleans, constant columns): the dword's 32 / w values lie wholly
-            // inside the tile and start at a multiple of four (lo is a multiple of 8), so they are read
-            // sixteen bytes at a time instead of one value per trip: few lanes have a dword here, and the
-            // rest of the workgroup waits for them.
-            const uint4 *z4 = (const uint4 *)(zz + ((uint32_t)lo >> (w - 1)));
+        if ((w & (w - 1)) == 0 && lo >= 0 && (uint32_t)lo + 32u <= (uint32_t)TILE * w) {
+            // Widths 1, 2, 4 and 8 (booleans, constant columns, enum tags): the dword's 32 / w values lie
+            // wholly inside the tile and start where the dword does (lo is a multiple of 8), so they are
+            // read sixteen or eight bytes at a time, without the loop: few lanes have a dword at the
+            // narrowest widths, and the rest of the workgroup waits for them.
+            const uint32_t i0 = (uint32_t)lo / w;
             v = 0;
             if (w == 1) {
+                const uint4 *z4 = (const uint4 *)(zz + i0);  // a multiple of 8
 #pragma unroll
                 for (int q = 0; q < 8; q++) { const uint4 z = z4[q]; v |= (z.x | z.y << 1 | z.z << 2 | z.w << 3) << (4 * q); }
-            } else {
+            } else if (w == 2) {
+                const uint4 *z4 = (const uint4 *)(zz + i0);  // a multiple of 4
 #pragma unroll
                 for (int q = 0; q < 4; q++) { const uint4 z = z4[q]; v |= (z.x | z.y << 2 | z.z << 4 | z.w << 6) << (8 * q); }
+            } else if (w == 4) {
+                const uint2 *z2 = (const uint2 *)(zz + i0);  // a multiple of 2
+#pragma unroll
+                for (int q = 0; q < 4; q++) { const uint2 z = z2[q]; v |= (z.x | z.y << 4) << (8 * q); }
+            } else {
+                v = zz[i0] | zz[i0 + 1] << 8 | zz[i0 + 2] << 16 | zz[i0 + 3] << 24;
             }
         } else {
             v = stream_dword(zz, lo, w, inv);
