@@ -26,7 +26,7 @@
 //   select   radix select on key = v - base, 12 bits a digit, from the top.  A short source is
 //            finished by one workgroup in one launch; a long one gets up to three launches of many
 //            workgroups, each of which either counts the next digit or, as soon as at most 2048
-//            keys share the resolved digits, gathers those keys for the finishing workgroup to sort.
+//            keys share the resolved digits, gathers those keys for the finishing workgroup.
 // Every kernel works on a whole submission (many arrays) through the same tile -> array map the
 // decoder uses, and every pass that an array does not need skips that array's memory.
 #pragma once
@@ -95,7 +95,7 @@ struct EncodeJob {
 };
 constexpr int SEL_LEVELS = 3;
 static_assert(SEL_LEVELS == sizeof(EncodeJob::match_min) / sizeof(unsigned long long), "one min / max pair per level");
-constexpr uint32_t GATHER_CAP = 2048;  // keys a level gathers: what the finishing workgroup sorts in LDS
+constexpr uint32_t GATHER_CAP = 2048;  // keys a level gathers: what the finishing workgroup holds in LDS
 enum SelAction : uint32_t {
     ACT_NONE = 0,    // nothing counted yet: the next step starts from this state
     ACT_HIST = 1,    // digit `lv` of the keys that share `prefix` is counted: in `hist` for S[0], else in lvl_hist[L - 1]
@@ -264,39 +264,6 @@ __device__ __forceinline__ void set_midpoint(EncodeJob &j, int64_t a, int64_t b,
 }
 
 // ---- 1. sample: bracket the median (or finish small arrays outright) --------------------------
-
-// Bitonic sort of up to SAMPLE keys in LDS by one workgroup of TH lanes (a multiple of 64).
-//
-// Pair p of a stage compares elements lo = (p / stride) * 2 * stride + p % stride and lo + stride.
-// A wave owns 64 consecutive pairs, so in a stage with stride <= 64 it touches exactly the 128
-// elements [128 * (p0 / 64), +128) and no other wave does: runs of such stages need no workgroup
-// barrier, only the wave's own LDS ordering (20 barriers instead of 78 for 4096 keys).
-// Sorts the first m keys (m a power of two, 2 <= m <= SAMPLE): a short array only pays for its
-// own length, not for the full sample.
-template <int TH>
-__device__ __forceinline__ void sort_keys_lds(uint64_t *sk, uint32_t m) {
-    uint32_t prev_stride = 128;  // the keys were written by other waves
-    for (uint32_t size = 2; size <= m; size <<= 1) {
-        for (uint32_t stride = size >> 1; stride > 0; stride >>= 1) {
-            if (stride > 64 || prev_stride > 64) {
-                __syncthreads();
-            } else {  // same wave wrote what it now reads: keep the accesses in program order
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-                __builtin_amdgcn_wave_barrier();
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-            }
-            prev_stride = stride;
-            for (uint32_t t = threadIdx.x; t < m / 2; t += TH) {
-                const uint32_t lo = 2 * t - (t & (stride - 1));  // index of the lower partner
-                const uint32_t hi = lo + stride;
-                const bool up = (lo & size) == 0;
-                const uint64_t x = sk[lo], y = sk[hi];
-                if ((x > y) == up) { sk[lo] = y; sk[hi] = x; }
-            }
-        }
-    }
-    __syncthreads();
-}
 
 // Two order statistics of up to SAMPLE keys, by one workgroup of SAMPLE_THREADS lanes that keep
 // their keys in registers: radix select on (key - smallest key), DIGIT_BITS bits a pass from the
@@ -966,7 +933,7 @@ __device__ __forceinline__ bool above_prefix(uint64_t key, const EncodeJob::SelS
 // one records it as S[L]), then
 //   - if every digit is resolved, the first workgroup derives the midpoint;
 //   - if at most GATHER_CAP keys share the resolved digits, the workgroups gather them (and the
-//     smallest key above them) for the finishing workgroup to sort;
+//     smallest key above them) for the finishing workgroup;
 //   - else they count the next digit of the keys that share the resolved digits.
 // No workgroup waits for another one: kernel boundaries are the only ordering.
 
@@ -1237,10 +1204,10 @@ __device__ __forceinline__ void for_each_select_key(const EncodeJob &job, uint32
 
 // One workgroup per listed array finishes its select, from wherever the earlier launches left it:
 //   - the bracket pass counted every digit there is (narrow bracket): one pick;
-//   - a level gathered the keys that share the resolved digits: they are sorted in LDS;
+//   - a level gathered the keys that share the resolved digits: their remaining digits are resolved in LDS;
 //   - otherwise the workgroup reads the source itself, digit by digit (histogram in LDS, no
 //     device-scope atomic), and as soon as KEEP or fewer keys share the resolved digits it gathers
-//     and sorts them, so a short source is read twice, not once per digit.  This is also the
+//     them into LDS and finishes there, so a short source is read twice, not once per digit.  This is also the
 //     (slow, exact) way out for a long source that SEL_LEVELS levels did not resolve: more than
 //     GATHER_CAP different keys of one array inside 2^-36 of its bracket.
 // Measured thresholds for "short" (2^12 .. 2^19 keys): a thousand 2^20-row arrays encode in
@@ -1277,24 +1244,53 @@ __global__ __launch_bounds__(THREADS) void enc_finish_select_kernel(EncodeJob *_
         const uint64_t x = (uint64_t)job.above_key < job.next_above ? (uint64_t)job.above_key : job.next_above;
         return (uint64_t)above_all < x ? (uint64_t)above_all : x;
     };
-    // sorts keep[0, cnt) and reads a and b off it
-    auto finish_sorted = [&](uint32_t cnt) {
-        uint32_t m = 2;
-        while (m < cnt) m <<= 1;
-        __syncthreads();
-        for (uint32_t i = cnt + tid; i < m; i += THREADS) keep[i] = ~0ull;  // padding sorts to the end
-        sort_keys_lds<THREADS>(keep, m);
-        if (tid == 0) {
-            const uint64_t key_a = keep[s.k];
-            uint64_t key_b = key_a;
-            if (even) key_b = s.k + 1 < cnt ? keep[s.k + 1] : above_so_far();
-            finish_select(job, key_a, key_b);
+    // keep[0, cnt) are the keys that share the s.lv resolved digits, s.k the rank of a among them:
+    // the remaining digits are resolved by the same count-and-descend steps, on the keys in LDS
+    // (2-3 us a digit; sorting the up to 2048 keys took 20-40 us, for two of them).
+    __shared__ unsigned long long lone;
+    auto finish_kept = [&](uint32_t cnt) {
+        __syncthreads();  // keep[] is written
+        uint64_t key_a = 0;
+        bool have_a = false;
+        while (!have_a) {  // uniform
+            if (s.lv == passes) { key_a = s.prefix; have_a = true; break; }
+            if (s.cnt == 1) {  // one key left under the prefix: it is a, whatever its lower digits
+                for (uint32_t i = tid; i < cnt; i += THREADS)
+                    if (shares_prefix(keep[i], s, bits)) lone = keep[i];
+                __syncthreads();
+                key_a = lone; have_a = true; break;
+            }
+            const uint32_t shift = digit_shift(bits, s.lv);
+            for (uint32_t b = tid; b < (uint32_t)BINS; b += THREADS) lh[b] = 0;
+            __syncthreads();
+            for (uint32_t i = tid; i < cnt; i += THREADS) {
+                const uint64_t key = keep[i];
+                if (shares_prefix(key, s, bits)) atomicAdd(&lh[(uint32_t)(key >> shift) & (BINS - 1)], 1u);
+            }
+            __syncthreads();
+            uint64_t unused;
+            s.action = ACT_HIST;
+            s = descend(s, lh, &sh, &unused, bits);
         }
+        // b for an even count: a again if rank k + 1 is still one of the keys equal to a, else the
+        // smallest key above a, inside the kept keys or above everything that shared their digits
+        const bool b_is_a = !even || (s.lv == passes && s.k + 1 < s.cnt);
+        if (!b_is_a) {
+            uint64_t above = ~0ull;
+            for (uint32_t i = tid; i < cnt; i += THREADS) {
+                const uint64_t key = keep[i];
+                if (key > key_a && key < above) above = key;
+            }
+            above = wave_min_u64(above);
+            if ((tid & 63) == 0 && above != ~0ull) atomicMin(&above_all, (unsigned long long)above);
+            __syncthreads();
+        }
+        if (tid == 0) finish_select(job, key_a, b_is_a ? key_a : above_so_far());
     };
     if (s.action == ACT_GATHER) {  // a level left the keys in `small`
         const uint32_t cnt = (uint32_t)s.cnt;  // == job.small_n
         for (uint32_t i = tid; i < cnt; i += THREADS) keep[i] = job.small[i];
-        finish_sorted(cnt);
+        finish_kept(cnt);
         return;
     }
     while (true) {  // uniform
@@ -1310,7 +1306,7 @@ __global__ __launch_bounds__(THREADS) void enc_finish_select_kernel(EncodeJob *_
             return;
         }
         if (s.cnt <= (uint64_t)KEEP) {
-            // gather the keys that share the resolved digits, sort them, read a and b off the list
+            // gather the keys that share the resolved digits and finish on them
             if (tid == 0) keep_n = 0;
             __syncthreads();
             uint64_t above = ~0ull;
@@ -1324,7 +1320,7 @@ __global__ __launch_bounds__(THREADS) void enc_finish_select_kernel(EncodeJob *_
             });
             above = wave_min_u64(above);
             if ((tid & 63) == 0 && above != ~0ull) atomicMin(&above_all, (unsigned long long)above);
-            finish_sorted((uint32_t)s.cnt);  // == keep_n
+            finish_kept((uint32_t)s.cnt);  // == keep_n
             return;
         }
         // count the next digit of the keys that share the resolved ones
