@@ -522,7 +522,7 @@ static int encode_batch_dev(DeviceCtx *ctx, const EncodeItem *items, size_t nd, 
     const size_t off_ctr = off_hist + (size_t)n_list * BINS * sizeof(uint32_t);
     const size_t off_lvl = off_ctr + (size_t)n_list * sizeof(BracketCounters);
     const size_t off_pend = off_lvl + (size_t)n_big * SEL_LEVELS * BINS * sizeof(uint32_t);
-    const size_t off_map = align_up(off_pend + ((size_t)n_big + 1) * sizeof(uint32_t), 64);  // tile -> array, written by the set-up kernel
+    const size_t off_map = align_up(off_pend + ((size_t)n_big + 2) * sizeof(uint32_t), 64);  // behind the list: the OR pass's flag; then tile -> array, written by the set-up kernel
     uint64_t all_tiles = 0;
     for (size_t i = 0; i < nd; i++) all_tiles += tiles_of(items[i].n);
     const size_t total = off_map + (nd > 1 ? (size_t)all_tiles * sizeof(uint32_t) : 0);
@@ -573,6 +573,7 @@ static int encode_batch_dev(DeviceCtx *ctx, const EncodeItem *items, size_t nd, 
     EncodeJob *d_jobs = (EncodeJob *)s->dev;
     const uint32_t *d_list = (const uint32_t *)((char *)s->dev + off_list);
     uint32_t *d_pend = (uint32_t *)((char *)s->dev + off_pend);
+    uint32_t *d_or_flag = d_pend + n_big + 1;
     const uint64_t *d_ts = (const uint64_t *)((char *)s->dev + off_ts);
     int st = hip_status(hipMemcpyAsync(s->dev, s->host, host_bytes, hipMemcpyHostToDevice, stream));
     if (st == ZBRA_OK) st = hip_status(hipMemsetAsync((char *)s->dev + off_hist, 0, off_map - off_hist, stream));
@@ -609,7 +610,7 @@ static int encode_batch_dev(DeviceCtx *ctx, const EncodeItem *items, size_t nd, 
                 hipLaunchKernelGGL(enc_bracket_kernel, dim3(gs), dim3(THREADS), 0, stream, d_jobs, d_ts, (uint32_t)nd, ntiles);
         }
         hipLaunchKernelGGL(enc_setup_kernel, dim3((unsigned)nd), dim3(THREADS), 0, stream, d_jobs, (uint32_t)nd, d_pend, small_max,
-                           d_ts, d_map);
+                           d_ts, d_map, d_or_flag);
         if (ntiles) {
             // the levels are only launched when an array could be too long for one finishing
             // workgroup (its length says so), and end at their first load when none was
@@ -624,7 +625,7 @@ static int encode_batch_dev(DeviceCtx *ctx, const EncodeItem *items, size_t nd, 
                 // 16 tiles instead, most of which end at their first look (a thousand 2^20-row
                 // arrays, two of them wide: 187 -> 47 us).
                 const unsigned go = nd == 1 ? gs : grid_for(ntiles / 16 + 1, 32768);
-                hipLaunchKernelGGL(enc_or_kernel, dim3(go), dim3(THREADS), 0, stream, d_jobs, d_ts, (uint32_t)nd, ntiles);
+                hipLaunchKernelGGL(enc_or_kernel, dim3(go), dim3(THREADS), 0, stream, d_jobs, d_ts, (uint32_t)nd, ntiles, d_or_flag);
             }
         }
         if (mode == ENCODE_FULL) {

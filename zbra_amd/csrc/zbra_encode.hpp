@@ -820,7 +820,8 @@ __device__ __forceinline__ void finish_run(EncodeJob &job, const EncodeJob::SelS
 // workgroup per array of enc_finish_select_kernel.
 __global__ __launch_bounds__(THREADS) void enc_setup_kernel(EncodeJob *__restrict__ jobs, uint32_t nd,
                                                              uint32_t *__restrict__ pending, uint64_t small_max,
-                                                             const uint64_t *__restrict__ tile_start, uint32_t *__restrict__ tile_map) {
+                                                             const uint64_t *__restrict__ tile_start, uint32_t *__restrict__ tile_map,
+                                                             uint32_t *__restrict__ or_flag) {
     const uint32_t a = blockIdx.x;
     if (a >= nd) return;
     // tile -> array table of the pack pass (one workgroup per tile there: a binary search over
@@ -903,6 +904,8 @@ __global__ __launch_bounds__(THREADS) void enc_setup_kernel(EncodeJob *__restric
         if (s.lv == j.passes) s.action = ACT_DONE;
     }
     if (threadIdx.x == 0) {
+        // one word for the whole submission: the OR pass ends at its first load unless some array's span wraps
+        if (j.n && j.need_or) *or_flag = 1u;
         j.S[0] = s;
         // A candidate list holds at most n / CAND_DIV values, so an array of up to CAND_DIV *
         // small_max values can only exceed small_max by reading all its values; those stay with
@@ -1348,7 +1351,10 @@ __global__ __launch_bounds__(THREADS) void enc_finish_select_kernel(EncodeJob *_
 
 __global__ __launch_bounds__(THREADS) void enc_or_kernel(EncodeJob *__restrict__ jobs,
                                                           const uint64_t *__restrict__ tile_start, uint32_t nd,
-                                                          uint64_t ntiles) {
+                                                          uint64_t ntiles, const uint32_t *__restrict__ or_flag) {
+    // set by the set-up kernel when an array may need this pass: without it the tens of thousands of
+    // workgroups of a large batch each looked up their arrays to find that none does (41 us)
+    if (*or_flag == 0) return;
     for_each_array_run(tile_start, nd, ntiles, [&](uint32_t a, uint64_t a_first, uint64_t t0, uint64_t t1) {
         const EncodeJob &job = jobs[a];
         if (!job.need_or) return;
