@@ -5,7 +5,9 @@ after one counted digit; a candidate list that overflows (two far-apart values, 
 one value at the median of otherwise wide data; a dense cluster of different values at the median
 of wide data (which no level resolves: the finishing workgroup reads on, digit by digit); sorted
 wide data; u32 values over their whole range; brackets of a few keys, dense (most of the values
-inside: per-lane counting columns) and sparse (shared histogram)."""
+inside: per-lane counting columns) and sparse (shared histogram); a median value that occurs several
+times in wide data, and middle ranks that lie far apart (what the finishing workgroup makes of the
+keys it holds in LDS)."""
 import os
 import subprocess
 import sys
@@ -59,11 +61,22 @@ def _shape(name, n, seed):
         return 1000 + rng.choice(np.array([0, 1, 2, 3], dtype=np.int64), n, p=[0.45, 0.03, 0.03, 0.49])
     if name == "few_keys_sparse":   # 48 equally likely values: a bracket of a few keys with a few per cent of the values, shared histogram
         return -5000 + rng.integers(0, 48, n, dtype=np.int64)
+    if name == "dup_at_median":     # wide data whose median value occurs seven times: for an even count b is a again
+        v = np.sort(rng.integers(-(1 << 62), 1 << 62, n, dtype=np.int64))
+        k = (n - 1) // 2
+        v[k - 3:k + 4] = v[k]
+        rng.shuffle(v)
+        return v
+    if name == "split_halves":      # the two middle ranks lie far apart: b is the smallest key above everything that shares a's digits
+        h = (n + 1) // 2
+        v = np.concatenate([-rng.integers(1 << 40, 1 << 62, h, dtype=np.int64), rng.integers(1 << 40, 1 << 62, n - h, dtype=np.int64)])
+        rng.shuffle(v)
+        return v
     raise KeyError(name)
 
 
 SHAPES = ["wide_uniform", "wide_40", "two_far", "three_far", "popular_in_wide", "cluster_in_wide", "sorted_wide", "extremes_mix",
-          "min_max_only", "few_keys_dense", "few_keys_sparse"]
+          "min_max_only", "few_keys_dense", "few_keys_sparse", "dup_at_median", "split_halves"]
 
 
 @pytest.fixture(scope="module")
