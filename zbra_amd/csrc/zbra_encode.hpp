@@ -366,8 +366,9 @@ __device__ __forceinline__ void select_two_ranks(const uint64_t (&key)[SAMPLE_PE
     out[1] = lo + prefix[1];
 }
 
-// One workgroup per array.
-__global__ __launch_bounds__(SAMPLE_THREADS) void enc_sample_kernel(EncodeJob *__restrict__ jobs, uint32_t nd, uint32_t use_bracket) {
+// One workgroup per array.  Held at 64 VGPRs (it wants 72 and spills 4) so that two workgroups of 1024
+// lanes fit a CU: three thousand 2^14-row arrays 121 -> 98 us, a single array the same 14 us.
+__global__ __launch_bounds__(SAMPLE_THREADS, 8) void enc_sample_kernel(EncodeJob *__restrict__ jobs, uint32_t nd, uint32_t use_bracket) {
     __shared__ SampleShared sh;
     const uint32_t a = blockIdx.x;
     if (a >= nd) return;
