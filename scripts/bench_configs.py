@@ -95,6 +95,7 @@ def main():
     ap.add_argument("--scale-log2", type=int, default=0, help="divide the row counts by 2^this (smoke runs)")
     ap.add_argument("--reps", type=int, default=10)
     ap.add_argument("--encode-only", action="store_true", help="no median check, no decode (kernel traces)")
+    ap.add_argument("--tile-order", type=int, default=2, help="force the decode's tile order: 0 plain, 1 one eighth per XCD, N groups of N (tuning; 2 = the library's choice)")
     ap.add_argument("--only", choices=["a", "b", "tags"], help="config 4: only the clustered (a) or the time-series (b) Int columns, or only the tag columns")
     args = ap.parse_args()
     global ENCODE_ONLY
@@ -102,7 +103,9 @@ def main():
     import torch
     import torch.distributed as dist
 
-    from zbra_amd import sharding, workloads
+    from zbra_amd import _lib, sharding, workloads
+    if args.tile_order != 2:
+        assert _lib.lib.zbra_tuning_set_decode_variant(2048, 512, 3, 0, args.tile_order) == 0
     rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     backend = os.environ.get("ZBRA_BENCH_BACKEND", "nccl")
