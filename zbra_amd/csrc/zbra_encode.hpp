@@ -721,28 +721,27 @@ struct BinPick {
     uint64_t before;     // keys in the bins below
 };
 struct BinPickShared {
-    uint64_t part[THREADS];
+    uint64_t part[THREADS / 64];  // the waves' totals
     BinPick pick;
 };
 __device__ __forceinline__ BinPick pick_bin(const uint32_t (&c)[SEL_PER], uint64_t k, BinPickShared *sh) {
-    const uint32_t tid = threadIdx.x;
+    const uint32_t tid = threadIdx.x, wave = tid >> 6, lane = tid & 63u;
     uint64_t sum = 0;
 #pragma unroll
     for (int i = 0; i < SEL_PER; i++) sum += c[i];
+    // inclusive prefix of the per-thread sums: inside the wave by shuffles, across the waves through
+    // their totals in LDS (three barriers in all; a Hillis-Steele scan over the 256 sums in LDS took 16)
+    uint64_t incl = sum;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint64_t add = __shfl_up(incl, o);
+        if (lane >= (uint32_t)o) incl += add;
+    }
     __syncthreads();  // the previous use of `sh` is over
-    sh->part[tid] = sum;
+    if (lane == 63) sh->part[wave] = incl;
     if (tid == 0) { sh->pick.next_bin = BINS; sh->pick.bin = 0; sh->pick.cnt = 0; sh->pick.before = 0; }
     __syncthreads();
-    // exclusive prefix of the per-thread sums (256 entries: a serial scan by every thread's own
-    // loop would be 256 LDS reads; a Hillis-Steele scan is 8 steps)
-    uint64_t incl = sum;
-    for (int o = 1; o < THREADS; o <<= 1) {
-        uint64_t add = tid >= (uint32_t)o ? sh->part[tid - o] : 0;
-        __syncthreads();
-        incl += add;
-        sh->part[tid] = incl;
-        __syncthreads();
-    }
+    for (uint32_t w = 0; w < wave; w++) incl += sh->part[w];
     const uint64_t before = incl - sum;
     if (k >= before && k < incl) {  // exactly one thread
         uint64_t run = before;
