@@ -845,12 +845,17 @@ __global__ __launch_bounds__(THREADS) void enc_setup_kernel(EncodeJob *__restric
             const uint64_t k = (j.n - 1) / 2;  // rank of a: n/2 - 1 for even n, n/2 for odd n
             bool whole_list = true;
             if (j.mode != SEL_FULL) {
-                j.below = 0; j.inb = 0;
+                // summed in registers: through `j` every step would be a load and a store that wait for each other
+                const BracketCounters *ctr = j.counters;
+                const uint64_t seg_cap = j.seg_cap;
+                uint64_t below = 0, inb = 0;
+#pragma unroll
                 for (int sgm = 0; sgm < CAND_SEGS; sgm++) {
-                    j.below += j.counters->slot[sgm].below;
-                    j.inb += j.counters->slot[sgm].inb;
-                    whole_list = whole_list && j.counters->slot[sgm].cand_count <= j.seg_cap;
+                    below += ctr->slot[sgm].below;
+                    inb += ctr->slot[sgm].inb;
+                    whole_list = whole_list && ctr->slot[sgm].cand_count <= seg_cap;
                 }
+                j.below = below; j.inb = inb;
             }
             // Rank k must fall inside the bracket (rank k+1, for even n, may also be the smallest
             // value above it).  The bracket pass has then counted the first digit of the keys inside
