@@ -107,7 +107,8 @@ constexpr int CAND_SEGS = 16;
 struct BracketCounters {
     struct Slot {
         unsigned long long below, inb, cand_count;  // cand_count may exceed seg_cap: the list is then unusable
-        unsigned long long pad[5];
+        unsigned long long first;                    // two-key bracket: values equal to its lower key
+        unsigned long long pad[4];
     } slot[CAND_SEGS];
 };
 static_assert(sizeof(BracketCounters::Slot) == 64, "one slot per 64-byte line");
@@ -687,12 +688,9 @@ __global__ __launch_bounds__(THREADS, ZBRA_BRACKET_WAVES) void enc_bracket_kerne
             if (threadIdx.x == 0) {
                 if (lbelow) atomicAdd(&ctr->below, lbelow);
                 if (linb) atomicAdd(&ctr->inb, linb);
-                // one- and two-key brackets: the histogram's bins are these counts
-                if (mode == SEL_BRACKET_ONE && linb) atomicAdd(&job.hist[0], (uint32_t)linb);
-                if (mode == SEL_BRACKET_TWO) {
-                    if (lfirst) atomicAdd(&job.hist[0], lfirst);
-                    if (linb - lfirst) atomicAdd(&job.hist[1], (uint32_t)(linb - lfirst));
-                }
+                // one- and two-key brackets: the histogram's bins are these counts, which the set-up kernel
+                // takes from the sixteen slots (a thousand workgroups adding to hist[0] queue behind each other)
+                if (mode == SEL_BRACKET_TWO && lfirst) atomicAdd(&ctr->first, (unsigned long long)lfirst);
                 lbelow = 0; linb = 0; lfirst = 0;
             }
             __syncthreads();
@@ -848,14 +846,20 @@ __global__ __launch_bounds__(THREADS) void enc_setup_kernel(EncodeJob *__restric
                 // summed in registers: through `j` every step would be a load and a store that wait for each other
                 const BracketCounters *ctr = j.counters;
                 const uint64_t seg_cap = j.seg_cap;
-                uint64_t below = 0, inb = 0;
+                uint64_t below = 0, inb = 0, first = 0;
 #pragma unroll
                 for (int sgm = 0; sgm < CAND_SEGS; sgm++) {
                     below += ctr->slot[sgm].below;
                     inb += ctr->slot[sgm].inb;
+                    first += ctr->slot[sgm].first;
                     whole_list = whole_list && ctr->slot[sgm].cand_count <= seg_cap;
                 }
                 j.below = below; j.inb = inb;
+                // a bracket of one or two keys: the bracket pass left its bins in the slots' counts
+                if (j.mode == SEL_BRACKET_HIST && j.hi_b - j.lo_b <= 1) {
+                    j.hist[0] = j.hi_b == j.lo_b ? (uint32_t)inb : (uint32_t)first;
+                    if (j.hi_b != j.lo_b) j.hist[1] = (uint32_t)(inb - first);
+                }
             }
             // Rank k must fall inside the bracket (rank k+1, for even n, may also be the smallest
             // value above it).  The bracket pass has then counted the first digit of the keys inside
