@@ -512,7 +512,7 @@ static int encode_batch_dev(DeviceCtx *ctx, const EncodeItem *items, size_t nd, 
         scratch_bytes += seg_cap_of(items[i]) * CAND_SEGS * sizeof(int64_t);
     }
     const size_t off_small = align_up(scratch_bytes, 256);  // gathered keys of the long arrays, behind the candidate lists
-    scratch_bytes = off_small + (size_t)n_big * GATHER_CAP * sizeof(uint64_t);
+    scratch_bytes = off_small + (size_t)n_big * GATHER_SEGS * GATHER_CAP * sizeof(uint64_t);
     const size_t off_ts = align_up(nd * sizeof(EncodeJob), 64);
     const size_t off_list = align_up(off_ts + (nd + 1) * sizeof(uint64_t), 64);  // the listed arrays
     const size_t host_bytes = off_list + (size_t)n_list * sizeof(uint32_t);      // what the host fills
@@ -560,7 +560,7 @@ static int encode_batch_dev(DeviceCtx *ctx, const EncodeItem *items, size_t nd, 
             h_list[i_list++] = (uint32_t)i;
             if (is_long(items[i])) {
                 j.lvl_hist = (uint32_t *)((char *)s->dev + off_lvl) + (size_t)i_big * SEL_LEVELS * BINS;
-                j.small = (uint64_t *)(scratch + off_small) + (size_t)i_big * GATHER_CAP;
+                j.small = (uint64_t *)(scratch + off_small) + (size_t)i_big * GATHER_SEGS * GATHER_CAP;
                 i_big++;
             }
         }

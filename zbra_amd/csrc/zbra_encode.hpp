@@ -79,9 +79,13 @@ struct EncodeJob {
     uint64_t flo, fhi;
     uint32_t *hist;      // BINS counters: the bracket pass's histogram (exact keys of a narrow bracket, first digit of a wide one)
     uint32_t *lvl_hist;  // SEL_LEVELS x BINS counters of the many-workgroup levels (long arrays only)
-    uint64_t *small;     // GATHER_CAP keys gathered by a level for the finishing workgroup (long arrays only)
-    uint32_t small_n;
+    // Keys gathered by a level for the finishing workgroup (long arrays only): GATHER_SEGS segments of
+    // GATHER_CAP keys, each with its own fill count (the level's workgroups take their room with a
+    // returning atomic, and hundreds of them on one word queue: 7 of that level's 25 us)
+    uint64_t *small;
+    uint32_t small_n[8];
     uint32_t pending;    // 1 = on the list of the many-workgroup levels
+    uint32_t pad_small;
     // smallest / largest key among those whose next digit level L counted (all equal: a run of one
     // value, which needs no further digit)
     unsigned long long match_min[3], match_max[3];
@@ -96,6 +100,8 @@ struct EncodeJob {
 constexpr int SEL_LEVELS = 3;
 static_assert(SEL_LEVELS == sizeof(EncodeJob::match_min) / sizeof(unsigned long long), "one min / max pair per level");
 constexpr uint32_t GATHER_CAP = 2048;  // keys a level gathers: what the finishing workgroup holds in LDS
+constexpr uint32_t GATHER_SEGS = 8;   // segments of the gather buffer, one fill count each
+static_assert(GATHER_SEGS == sizeof(EncodeJob::small_n) / sizeof(uint32_t), "one count per segment");
 enum SelAction : uint32_t {
     ACT_NONE = 0,    // nothing counted yet: the next step starts from this state
     ACT_HIST = 1,    // digit `lv` of the keys that share `prefix` is counted: in `hist` for S[0], else in lvl_hist[L - 1]
@@ -1100,12 +1106,13 @@ __device__ __forceinline__ void level_one(EncodeJob *__restrict__ jobs, uint32_t
     __syncthreads();
     if (gather) {
         const uint32_t cnt = stage_n < GATHER_CAP ? stage_n : GATHER_CAP;
-        if (tid == 0 && cnt) stage_base = atomicAdd(&job.small_n, cnt);
+        const uint32_t seg = w % GATHER_SEGS;
+        if (tid == 0 && cnt) stage_base = atomicAdd(&job.small_n[seg], cnt);
         __syncthreads();
         if (cnt) {
             const uint32_t at = stage_base;
             for (uint32_t i = tid; i < cnt; i += THREADS)
-                if (at + i < GATHER_CAP) job.small[at + i] = stage[i];  // always true while nobody writes the source
+                if (at + i < GATHER_CAP) job.small[(size_t)seg * GATHER_CAP + at + i] = stage[i];  // always true while nobody writes the source
         }
     } else {
         uint32_t *gh = job.lvl_hist + (size_t)(L - 1) * BINS;
@@ -1300,8 +1307,17 @@ __global__ __launch_bounds__(THREADS) void enc_finish_select_kernel(EncodeJob *_
         if (tid == 0) finish_select(job, key_a, b_is_a ? key_a : above_so_far());
     };
     if (s.action == ACT_GATHER) {  // a level left the keys in `small`
-        const uint32_t cnt = (uint32_t)s.cnt;  // == job.small_n
-        for (uint32_t i = tid; i < cnt; i += THREADS) keep[i] = job.small[i];
+        const uint32_t cnt = (uint32_t)s.cnt;  // == the sum of job.small_n
+        uint32_t m[GATHER_SEGS], at = 0;
+#pragma unroll
+        for (uint32_t seg = 0; seg < GATHER_SEGS; seg++) m[seg] = job.small_n[seg];  // one load for all of them
+        const uint64_t *small = job.small;
+#pragma unroll
+        for (uint32_t seg = 0; seg < GATHER_SEGS; seg++) {  // uniform
+            for (uint32_t i = tid; i < m[seg]; i += THREADS)
+                if (at + i < KEEP) keep[at + i] = small[(size_t)seg * GATHER_CAP + i];
+            at += m[seg];
+        }
         finish_kept(cnt);
         return;
     }
