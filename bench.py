@@ -162,17 +162,102 @@ def cpu_baseline(n_sample: int, budget_s: float):
                           "sample": "same rows cut into one chunk per thread"}}
 
 
+def claim_stdout() -> int:
+    """stdout carries ONE JSON line.  Libraries print there too (RCCL its version banner when the
+    first communicator is made, gloo its peer count), so from here on file descriptor 1 of this
+    process is stderr, and the line goes to the returned duplicate of the real stdout."""
+    sys.stdout.flush()
+    real = os.dup(1)
+    os.dup2(2, 1)
+    return real
+
+
+def emit_line(real_stdout: int, line: dict):
+    os.write(real_stdout, (json.dumps(line) + "\n").encode())
+
+
+def force_dist() -> bool:
+    """ZBRA_BENCH_FORCE_DIST=1: a single rank also creates its process group and goes through every
+    collective of the many-rank job (barriers, the two all-reduces, the gather of the ranks'
+    reports): the one-GPU rehearsal of the code an 8-GPU run executes."""
+    return os.environ.get("ZBRA_BENCH_FORCE_DIST") == "1"
+
+
+def rendezvous_env():
+    """A process group of one rank that no launcher prepared still needs a rendezvous address."""
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    if "MASTER_PORT" not in os.environ:
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            os.environ["MASTER_PORT"] = str(s.getsockname()[1])
+    os.environ.setdefault("RANK", "0")
+    os.environ.setdefault("WORLD_SIZE", "1")
+
+
+def device_identity(torch, gpu: int) -> str:
+    """PCI address of the device this rank decodes on (the same GPU has the same address in every
+    process of the node, whatever index it has there), or its UUID where torch does not tell."""
+    p = torch.cuda.get_device_properties(gpu)
+    try:
+        return "%04x:%02x:%02x" % (p.pci_domain_id, p.pci_bus_id, p.pci_device_id)
+    except AttributeError:
+        return str(getattr(p, "uuid", f"index:{gpu}"))
+
+
+def job_report(elapsed_s: float, units: float, step_ms: float, device_id: str, red_dev, one_gpu_per_rank: bool):
+    """The whole job from every rank's numbers: (slowest rank's time, all ranks' units, the fields
+    the JSON line carries about the ranks).  Every rank gets the same answer.  Two ranks of a
+    one-rank-per-GPU job on ONE device would report a rate no 8-GPU node has: that ends the job with
+    exit code 3 on every rank."""
+    from zbra_amd import sharding
+    total_s, total_units = sharding.job_totals(elapsed_s, units, red_dev)
+    per = sharding.gather_ranks({"rank": int(os.environ.get("RANK", "0")), "ms": round(step_ms, 4), "device": device_id})
+    fields = {"ranks_seen": sharding.ranks_seen(), "per_rank_ms": [p["ms"] for p in per],
+              "per_rank_device": [p["device"] for p in per]}
+    assert [p["rank"] for p in per] == list(range(len(per))), per
+    clash = sharding.shared_devices(fields["per_rank_device"]) if one_gpu_per_rank else []
+    if clash:
+        print(f"bench.py: ranks share a device: {clash} in {fields['per_rank_device']}", file=sys.stderr, flush=True)
+        raise SystemExit(3)
+    return total_s, total_units, fields
+
+
+def dry_rank():
+    """Launcher and reduction rehearsal on a machine without a GPU (ZBRA_BENCH_DRY_RANK=1): the rank
+    joins a gloo group, goes through the barriers and the whole-job reduction with made-up times and
+    a made-up device name (ZBRA_BENCH_DRY_CLASH=1: the same name on every rank), and rank 0 prints
+    where it sits in the job."""
+    real_stdout = claim_stdout()
+    import torch.distributed as dist
+    rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    grouped = world > 1 or force_dist()
+    if grouped:
+        rendezvous_env()
+        dist.init_process_group(backend="gloo")
+        dist.barrier()
+    name = "dry:0" if os.environ.get("ZBRA_BENCH_DRY_CLASH") == "1" else f"dry:{local_rank}"
+    try:
+        elapsed, units, fields = job_report(0.001 * (rank + 1), 100.0, 1.0 + rank, name, "cpu", True)
+        if rank == 0:
+            line = {"dry": True, "rank": rank, "n_gpus": world, "job_seconds": elapsed, "job_units": units,
+                    "config": {"partitioning": f"columns x{world}, no collectives"}}
+            line.update(fields)
+            emit_line(real_stdout, line)
+    finally:
+        if grouped:
+            dist.destroy_process_group()
+
+
 def main():
     args = parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # the parent only launches: torch is not imported and HIP is not touched in this process
         sys.exit(spawn_ranks(args.gpus, sys.argv[1:]))
     if os.environ.get("ZBRA_BENCH_DRY_RANK") == "1":
-        # launcher rehearsal on a machine without a GPU: say where this rank sits in the job and stop
-        rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
-        print(json.dumps({"dry": True, "rank": rank, "n_gpus": world,
-                          "config": {"partitioning": f"columns x{world}, no collectives"}}), flush=True)
+        dry_rank()
         return
+    real_stdout = claim_stdout()
     import torch
     import torch.distributed as dist
 
@@ -184,10 +269,14 @@ def main():
     # one rank per GPU; ZBRA_BENCH_BACKEND=gloo lets several ranks rehearse on one GPU (the
     # collective then runs on CPU tensors), the default nccl (= RCCL) needs a GPU per rank
     backend = os.environ.get("ZBRA_BENCH_BACKEND", "nccl")
+    if backend == "nccl" and local_rank >= torch.cuda.device_count():
+        raise SystemExit(f"bench.py: rank {rank} has no GPU of its own (LOCAL_RANK {local_rank}, {torch.cuda.device_count()} visible)")
     gpu = local_rank if backend == "nccl" else local_rank % torch.cuda.device_count()
     torch.cuda.set_device(gpu)
     dev = torch.device("cuda", gpu)
-    if world > 1:
+    grouped = world > 1 or force_dist()
+    if grouped:
+        rendezvous_env()
         if backend == "nccl":
             dist.init_process_group(backend="nccl", device_id=dev)
         else:
@@ -239,7 +328,7 @@ def main():
     # -- timed region ------------------------------------------------------------------------
     ev0 = torch.cuda.Event(enable_timing=True)  # events on the stream the kernels run on
     ev1 = torch.cuda.Event(enable_timing=True)
-    if world > 1:
+    if grouped:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -248,13 +337,15 @@ def main():
         step()
     ev1.record()
     torch.cuda.synchronize()
-    if world > 1:
+    own_elapsed = time.perf_counter() - t0  # this rank's K steps, before it waits for the others
+    if grouped:
         dist.barrier()
     elapsed = time.perf_counter() - t0
     kernel_ms = ev0.elapsed_time(ev1) / args.steps  # per decode launch (plan + tile kernel)
 
-    # whole job: slowest rank's time, every rank's decoded bytes
-    elapsed, decoded_bytes = sharding.job_totals(elapsed, 8.0 * n * args.steps, red_dev)
+    # whole job: slowest rank's time, every rank's decoded bytes, and what each rank ran on
+    elapsed, decoded_bytes, rank_fields = job_report(elapsed, 8.0 * n * args.steps, own_elapsed / args.steps * 1e3,
+                                                     device_identity(torch, gpu), red_dev, backend == "nccl")
 
     # -- encode timing (secondary; same config names encode + decode) -------------------------
     encode = None
@@ -288,6 +379,7 @@ def main():
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
+            "warmup_total": prewarm + args.warmup,  # untimed decodes before the timed region: set-up decodes + --warmup
             "ms_per_step": round(elapsed / args.steps * 1e3, 4),
             "higher_is_better": True,
             "scaling": "weak",
@@ -303,12 +395,15 @@ def main():
                          "kernel": "decode_tiles_kernel", "kernel_ms": round(kernel_ms, 4),
                          "algorithmic_bytes_per_launch": int(algo_bytes)},
         }
+        line.update(rank_fields)
+        line["collectives"] = (f"{dist.get_backend()} process group: barrier around the timed region, max/sum all-reduce and a gather "
+                               "of the ranks' reports; none on the data path") if grouped else "none (single process, no group)"
         if encode is not None:
             line["encode"] = encode
         if world == 1 and args.cpu_seconds > 0:
             line["cpu_baseline"] = cpu_baseline(min(n, 1 << 25), args.cpu_seconds)
-        print(json.dumps(line), flush=True)
-    if world > 1:
+        emit_line(real_stdout, line)
+    if grouped:
         dist.destroy_process_group()
 
 

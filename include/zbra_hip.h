@@ -216,7 +216,8 @@ int zbra_hip_decode_batch_dev(const zbra_array_desc *descs, size_t nd, zbra_dev_
 
 /* zbra_hip_decode_batch_dev for callers that cannot allocate: code under HIP graph capture, tight
  * serving loops, harnesses that forbid hipMalloc.  It has no counterpart in the reference.  Same
- * arguments, same results and same kernels as zbra_hip_decode_batch_dev, but the decode plans, the
+ * arguments and same results as zbra_hip_decode_batch_dev; always the default tile kernel (never the
+ * warm-up route that zbra_hip_decode_batch_dev picks for narrow submissions).  The decode plans, the
  * tiles-per-array scan and the tile -> array table live in a fixed array of device memory inside
  * the library (about 4.2 MiB on every GPU the library runs on, held until the process ends), and
  * the descriptors travel in kernel arguments: the call is kernel launches only, no hipMalloc, no
@@ -229,7 +230,8 @@ int zbra_hip_decode_batch_dev(const zbra_array_desc *descs, size_t nd, zbra_dev_
  * streams, different threads) race; calls on one stream are ordered and safe.  The per-device
  * set-up (context and the array's address on that device) runs in zbra_hip_init() or in any earlier
  * call on the device; when this call is the first one on a device it runs the set-up itself, which
- * creates a stream: call zbra_hip_init() beforehand where even that is not allowed. */
+ * creates a stream: call zbra_hip_init() beforehand where even that is not allowed (under graph
+ * capture it is not: the captured call must not be the device's first). */
 #define ZBRA_HIP_NOALLOC_MAX_ARRAYS 4096
 #define ZBRA_HIP_NOALLOC_MAX_TILES (1u << 20)
 int zbra_hip_decode_batch_dev_noalloc(const zbra_array_desc *descs, size_t nd, zbra_dev_result *d_results, void *stream);

@@ -11,10 +11,10 @@ import pytest
 from conftest import ROOT
 
 
-def _declared():
-    text = open(os.path.join(ROOT, "include", "zbra_hip.h")).read()
+def _declared(header="zbra_hip.h", prefix="zbra_hip_"):
+    text = open(os.path.join(ROOT, "include", header)).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-    return sorted(set(re.findall(r"\b(zbra_hip_\w+)\s*\(", text)))
+    return sorted(set(re.findall(r"\b(" + prefix + r"\w+)\s*\(", text)))
 
 
 def test_header_symbols_exported_and_bound():
@@ -27,6 +27,12 @@ def test_header_symbols_exported_and_bound():
     out = subprocess.check_output(["nm", "-D", "--defined-only", _lib.LIB_PATH], text=True)
     exported = set(re.findall(r"\bT (zbra_hip_\w+)", out))
     assert exported == set(declared)
+    # everything else the library exports for C callers is a test/tuning hook, and every one of those
+    # is declared in the header that says so: no undeclared entry point
+    hooks = _declared("zbra_hip_tuning.h", "zbra_tuning_")
+    assert len(hooks) == 4
+    c_symbols = {m for m in re.findall(r"\b[TDB] (\w+)", out) if not m.startswith("_Z") and not m.startswith("__")}
+    assert c_symbols == set(declared) | set(hooks), sorted(c_symbols ^ (set(declared) | set(hooks)))
 
 
 def test_header_compiles_as_c():

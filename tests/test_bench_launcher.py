@@ -53,6 +53,39 @@ def test_only_rank0_reaches_stdout_and_gpus_flag_launches(tmp_path):
                          timeout=120)
     assert out.returncode == 0, out.stderr
     lines = [ln for ln in out.stdout.splitlines() if ln.strip()]
-    assert len(lines) == 1
+    assert len(lines) == 1, out.stdout  # what libraries print on stdout (gloo's peer count, RCCL's banner) must not reach it
     doc = json.loads(lines[0])
     assert doc["n_gpus"] == 2 and doc["rank"] == 0 and doc["config"]["partitioning"].startswith("columns x2")
+    # the dry ranks went through the job's collectives (gloo): slowest rank's time, both ranks' units,
+    # and one report per rank, in rank order
+    assert doc["ranks_seen"] == 2 and doc["per_rank_device"] == ["dry:0", "dry:1"] and doc["per_rank_ms"] == [1.0, 2.0]
+    assert doc["job_seconds"] == 0.002 and doc["job_units"] == 200.0
+
+
+def _dry_env(**extra):
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
+    env["ZBRA_BENCH_DRY_RANK"] = "1"
+    env.update(extra)
+    return env
+
+
+def test_two_ranks_on_one_device_fail_the_job():
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], env=_dry_env(ZBRA_BENCH_DRY_CLASH="1"),
+                         capture_output=True, text=True, timeout=120)
+    assert out.returncode == 3, (out.returncode, out.stderr)
+    assert "ranks share a device" in out.stderr and not out.stdout.strip()
+
+
+def test_single_rank_can_be_forced_through_the_collectives():
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1"], env=_dry_env(ZBRA_BENCH_FORCE_DIST="1"),
+                         capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr
+    assert len(out.stdout.strip().splitlines()) == 1, out.stdout
+    doc = json.loads(out.stdout)
+    assert doc["ranks_seen"] == 1 and doc["per_rank_device"] == ["dry:0"] and doc["job_units"] == 100.0
+
+
+def test_shared_devices():
+    from zbra_amd import sharding
+    assert sharding.shared_devices(["a", "b", "c"]) == []
+    assert sharding.shared_devices(["a", "b", "a", "b", "c"]) == ["a", "b"]

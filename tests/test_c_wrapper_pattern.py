@@ -30,3 +30,17 @@ def test_wrapper_pattern_refuses_without_device():
     _ensure_built()
     p = subprocess.run([EXE], capture_output=True, text=True, timeout=60)
     assert p.returncode == 2 and "need a GPU" in p.stdout
+
+
+MULTI = os.path.join(ROOT, "tests", "c", "test_multi_device")
+
+
+@pytest.mark.gpu
+def test_every_device_from_one_process():
+    """tests/c/test_multi_device.c: two threads per device of zbra_hip_device_count (device-resident
+    calls incl. the no-allocation decode, and host-pointer calls), all at once, against the oracle."""
+    if not os.path.exists(MULTI):
+        subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "tests", "c")])
+    p = subprocess.run([MULTI], capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stdout + p.stderr
+    assert " 0 failures" in p.stdout and "device 0 at " in p.stdout

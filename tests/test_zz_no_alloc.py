@@ -105,3 +105,54 @@ def test_noalloc_rejects_what_its_scratch_cannot_hold(env):
         device.decode_batch_dev_noalloc(over)
     torch.cuda.synchronize()
     assert "scratch" in L.strerror(L.ERR_NOALLOC_LIMIT)
+
+
+def test_noalloc_under_graph_capture_and_replay(env):
+    """The callers the entry point is for: a stream under HIP graph capture, where an allocation, a
+    copy from pageable memory or a synchronisation fails the capture.  One call is captured after
+    zbra_hip_init(), then replayed twice over CHANGED encoded bytes (same frame lengths, so the
+    descriptors baked into the graph still hold); each replay must produce the oracle's values, and
+    the device's free memory must be what it was before the capture."""
+    torch, device, oc, L = env
+    assert L.lib.zbra_hip_init() == 0
+    specs = [("narrow", 200001), ("tags", 70001), ("w31", 40961), ("narrow", 2049)]
+    subs = [_submission(torch, oc, L, specs, seed) for seed in (11, 12, 13)]
+    # same layout for all three data sets: equal encoded lengths, blob rebuilt at the first one's offsets
+    lens = [[len(e) for e in sub[1]] for sub in subs]
+    assert lens[0] == lens[1] == lens[2], lens
+    offs = subs[0][3]
+    blobs = []
+    for sub in subs:
+        b = bytearray(subs[0][4].numel())
+        for e, o in zip(sub[1], offs):
+            b[o:o + len(e)] = e
+        blobs.append(torch.frombuffer(b, dtype=torch.uint8).cuda())
+    d_blob = blobs[0].clone()
+    cols0, _, kinds, _, _ = subs[0]
+    outs, items = [], []
+    for i, v in enumerate(cols0):
+        o = torch.full((v.size + 2,), -3, dtype=torch.int64 if kinds[i] == L.ELEM_I64 else torch.int32, device="cuda")
+        outs.append(o)
+        items.append((d_blob.data_ptr() + offs[i], lens[0][i], v.size, o.data_ptr() + o.element_size(), kinds[i]))
+    descs = device.make_descs(items)
+    res = device.new_results(len(items), "cuda")
+    torch.cuda.synchronize()
+    free_before = torch.cuda.mem_get_info()[0]
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph, stream=torch.cuda.Stream()):
+        device.decode_batch_dev_noalloc(descs, res)          # on the capturing stream
+    for o in outs:
+        assert (o == -3).all()                                # captured, not run
+    for k in (1, 2, 0):
+        d_blob.copy_(blobs[k])
+        for o in outs:
+            o.fill_(-3)
+        graph.replay()
+        torch.cuda.synchronize()
+        for i, v in enumerate(subs[k][0]):
+            got = outs[i].cpu().numpy()
+            want = v if v.dtype == np.int64 else v.view(np.int32)
+            assert np.array_equal(got[1:-1], want) and got[0] == -3 and got[-1] == -3, (k, specs[i])
+        for r in device.read_results(res):
+            assert r.status == 0
+    assert torch.cuda.mem_get_info()[0] >= free_before - (4 << 20)   # the graph object itself is all that was added

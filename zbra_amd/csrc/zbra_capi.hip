@@ -4,6 +4,7 @@
 
 #include <cstdio>
 #include <cstdlib>
+#include <atomic>
 #include <cstring>
 #include <map>
 #include <mutex>
@@ -16,6 +17,7 @@
 #include "zbra_file.hpp"
 #include "zbra_offsets.hpp"
 #include "zbra_enum.hpp"
+#include "zbra_hip_tuning.h"
 
 namespace zbra {
 
@@ -82,11 +84,14 @@ struct DecodeConfig {
     unsigned grid_cap = 0x7FFFFFFFu;  // one workgroup per tile
 };
 
+struct Tuning;
+static const Tuning &tuning();
+
 // Work-items one dispatch may have: the grid of an AQL packet is 32 bits wide in work-items, and
 // a larger launch is not refused but silently runs the low 32 bits' worth of workgroups.  Launches
 // with one workgroup per tile are cut (decode) or capped (pack) by this.
 // zbra_tuning_set_launch_limit lowers it so that tests reach the cut with small inputs.
-static uint64_t g_launch_limit = 0xFFFFFFFFull;
+static uint64_t launch_limit();
 
 template <int DT, int TH>
 static void launch_decode_t(const DecodeConfig &c, hipStream_t stream, const DecodePlan *plans, const uint64_t *ts,
@@ -94,7 +99,7 @@ static void launch_decode_t(const DecodeConfig &c, hipStream_t stream, const Dec
     // c.xcd: 2 = the order the caller worked out (decode_tile_order); anything else forces that order (tuning)
     const uint32_t want = c.xcd == 2 ? order : (uint32_t)c.xcd;
     // tiles per launch: a multiple of 8 (whole rounds of the XCDs) within the dispatch limit
-    uint64_t per = g_launch_limit / TH & ~7ull;
+    uint64_t per = launch_limit() / TH & ~7ull;
     if (per == 0) per = 8;
     for (uint64_t done = 0; done < all_tiles; done += per) {
         const uint64_t base = first_tile + done;
@@ -127,34 +132,68 @@ static const DecodeShape kDecodeShapes[] = {  // the default and the alternative
     {512, 64, launch_decode_t<512, 64>},
 };
 
-static DecodeLauncher g_decode_fn = launch_decode_t<2048, 512>;
-static DecodeConfig g_decode_cfg;
-static bool apply_variant(DecodeConfig &c, int t, int th, int n, int d) {
+// Launch policy of the process: the defaults, what the environment overrides at the first call, and
+// what the zbra_tuning_set_* hooks (include/zbra_hip_tuning.h) change afterwards.  A call reads the
+// current snapshot through tuning(); a hook publishes a modified copy, so a call running on another
+// thread sees either the old policy or the new one, never a mixture of half-written fields.
+// Superseded snapshots are not freed (a call may still hold one; the hooks are test and tuning aids).
+struct Tuning {
+    DecodeConfig decode;
+    DecodeLauncher decode_fn = launch_decode_t<2048, 512>;
+    uint64_t launch_limit = 0xFFFFFFFFull;
+    // the warm-up route of narrow submissions (see launch_decode_submission): packed bytes per warmed
+    // chunk (0 = off), widest array that takes it, smallest submission that does
+    uint64_t warm_bytes = (uint64_t)64 << 20;
+    uint32_t warm_bits = 6;
+    uint64_t warm_min_bytes = (uint64_t)8 << 20;
+    int enum_reverse = -1;  // -1: by size; 0 / 1 force the order of the enum write pass
+};
+static bool apply_variant(Tuning &t, int tile, int th, int n, int d) {
     for (const DecodeShape &sh : kDecodeShapes)
-        if (sh.tile == t && sh.threads == th) {
-            c.tile = t; c.threads = th; c.nt = n & 3; c.direct = d != 0;
-            g_decode_fn = sh.fn;
+        if (sh.tile == tile && sh.threads == th) {
+            t.decode.tile = tile; t.decode.threads = th; t.decode.nt = n & 3; t.decode.direct = d != 0;
+            t.decode_fn = sh.fn;
             return true;
         }
     return false;
 }
-static const DecodeConfig &decode_config() {
-    static const bool once = [] {
-        DecodeConfig &c = g_decode_cfg;
-        if (const char *e = getenv("ZBRA_HIP_DECODE_VARIANT")) {
-            int t = 0, th = 0, n = 0, d = 0;
-            if (sscanf(e, "%d:%d:%d:%d", &t, &th, &n, &d) == 4) apply_variant(c, t, th, n, d);
-        }
-        if (const char *e = getenv("ZBRA_HIP_DECODE_XCD")) c.xcd = atoi(e);  // 0 plain, 1 chunked, 2 by bits per value, >= 4 groups of that many tiles
-        if (const char *e = getenv("ZBRA_HIP_DECODE_GRID")) {
-            const long v = atol(e);
-            if (v > 0) c.grid_cap = (unsigned)v;
-        }
-        return true;
-    }();
-    (void)once;
-    return g_decode_cfg;
+static std::atomic<const Tuning *> g_tuning{nullptr};
+static std::mutex g_tuning_mu;  // writers: the first call's set-up and the hooks
+static const Tuning *tuning_init_locked() {
+    const Tuning *cur = g_tuning.load(std::memory_order_acquire);
+    if (cur) return cur;
+    Tuning *t = new Tuning();
+    if (const char *e = getenv("ZBRA_HIP_DECODE_VARIANT")) {
+        int tile = 0, th = 0, n = 0, d = 0;
+        if (sscanf(e, "%d:%d:%d:%d", &tile, &th, &n, &d) == 4) apply_variant(*t, tile, th, n, d);
+    }
+    if (const char *e = getenv("ZBRA_HIP_DECODE_XCD")) t->decode.xcd = atoi(e);  // 0 plain, 1 chunked, 2 by bits per value, >= 4 groups of that many tiles
+    if (const char *e = getenv("ZBRA_HIP_DECODE_GRID")) {
+        const long v = atol(e);
+        if (v > 0) t->decode.grid_cap = (unsigned)v;
+    }
+    if (const char *e = getenv("ZBRA_HIP_DECODE_WARM"))
+        if (atoi(e) == 0) t->warm_bytes = 0;
+    g_tuning.store(t, std::memory_order_release);
+    return t;
 }
+static const Tuning &tuning() {
+    const Tuning *t = g_tuning.load(std::memory_order_acquire);
+    if (t) return *t;
+    std::lock_guard<std::mutex> g(g_tuning_mu);
+    return *tuning_init_locked();
+}
+// Publishes a copy of the current policy changed by `change` (which returns false to refuse).
+template <typename F>
+static bool retune(F &&change) {
+    std::lock_guard<std::mutex> g(g_tuning_mu);
+    Tuning *t = new Tuning(*tuning_init_locked());
+    if (!change(*t)) { delete t; return false; }
+    g_tuning.store(t, std::memory_order_release);
+    return true;
+}
+static uint64_t launch_limit() { return tuning().launch_limit; }
+static const DecodeConfig &decode_config() { return tuning().decode; }
 // Tiles of one array: u32 outputs use tiles of twice the values (see decode_tiles_kernel).
 static inline uint64_t decode_tiles_of(uint64_t count, uint32_t kind) {
     const uint64_t t = (uint64_t)decode_config().tile * (kind == ZBRA_ELEM_U32 ? 2 : 1);
@@ -184,11 +223,12 @@ static inline uint32_t decode_tile_order(uint64_t encoded_bytes, uint64_t values
 
 static void launch_decode(hipStream_t stream, const DecodePlan *plans, const uint64_t *ts, const uint32_t *tmap, uint32_t nd,
                           uint64_t ntiles, uint32_t order) {
-    g_decode_fn(decode_config(), stream, plans, ts, tmap, nd, 0, ntiles, order);
+    const Tuning &t = tuning();
+    t.decode_fn(t.decode, stream, plans, ts, tmap, nd, 0, ntiles, order);
 }
 
-// Narrow submissions (every array at most g_warm_bits encoded bits per value, g_warm_min_bytes or more
-// in all) are decoded in chunks of about g_warm_bytes packed bytes: warm_tiles_kernel reads a
+// Narrow submissions (every array at most Tuning::warm_bits encoded bits per value, warm_min_bytes or more
+// in all) are decoded in chunks of about warm_bytes packed bytes: warm_tiles_kernel reads a
 // chunk's packed bytes into the memory-side cache, then the tile kernel decodes it with plain
 // loads and without LDS (each lane reads the dwords that hold its own values; lanes overlap, which
 // the caches now absorb).  Measured with the caches emptied before every launch (scripts/ab_decode_cold.py,
@@ -196,9 +236,6 @@ static void launch_decode(hipStream_t stream, const DecodePlan *plans, const uin
 // 0.354, of width 6: 0.406 -> 0.385; from width 7 up the warm-up costs what it saves, and so it does for
 // u32 outputs from width 4 up (2^29 tags of width 4: 0.403 -> 0.446 ms), whose limit is half the width.
 // ZBRA_HIP_DECODE_WARM=0 turns it off; zbra_tuning_set_decode_warm changes chunk and width limit.
-static uint64_t g_warm_bytes = [] { const char *e = getenv("ZBRA_HIP_DECODE_WARM"); return e && atoi(e) == 0 ? (uint64_t)0 : (uint64_t)64 << 20; }();
-static uint32_t g_warm_bits = 6;
-static uint64_t g_warm_min_bytes = (uint64_t)8 << 20;
 
 struct WarmPlan {
     bool on = false;
@@ -206,14 +243,15 @@ struct WarmPlan {
     uint32_t tiles_per_wg = 1;
 };
 static bool warm_route_available() {
-    return g_warm_bytes && decode_config().tile == 2048 && !decode_config().direct;
+    const Tuning &t = tuning();
+    return t.warm_bytes && t.decode.tile == 2048 && !t.decode.direct;
 }
 // Does this array belong on the warm-up route?  Bits per value as the frame's length says them: exact for
 // a well-formed E (a wrong guess costs time, nothing else).  u32 outputs are half as wide: the same packed
 // bytes buy half the output, so half the width pays.  Arrays too short to tell go either way (`dflt`).
 static bool warm_narrow(const zbra_array_desc &d, bool dflt) {
     if (d.count < 8 || d.len <= 13) return dflt;
-    return (d.len - 13) * 8 / d.count * (d.kind == ZBRA_ELEM_U32 ? 2 : 1) <= g_warm_bits;
+    return (d.len - 13) * 8 / d.count * (d.kind == ZBRA_ELEM_U32 ? 2 : 1) <= tuning().warm_bits;
 }
 // Chunking of `ntiles` tiles that hold `bytes` encoded bytes.
 static WarmPlan warm_plan_of(uint64_t ntiles, uint64_t bytes) {
@@ -221,14 +259,14 @@ static WarmPlan warm_plan_of(uint64_t ntiles, uint64_t bytes) {
     if (!ntiles) return wp;
     wp.on = true;
     const uint64_t tile_bytes = bytes / ntiles ? bytes / ntiles : 1;
-    wp.tiles_per_chunk = (g_warm_bytes / tile_bytes) & ~7ull;
+    wp.tiles_per_chunk = (tuning().warm_bytes / tile_bytes) & ~7ull;
     if (wp.tiles_per_chunk < 64) wp.tiles_per_chunk = 64;
     const uint64_t per_wg = 65536 / tile_bytes;
     wp.tiles_per_wg = (uint32_t)(per_wg < 1 ? 1 : per_wg > 256 ? 256 : per_wg);
     return wp;
 }
 static WarmPlan warm_plan_for(const zbra_array_desc *descs, size_t nd, uint64_t ntiles, uint64_t all_bytes) {
-    if (!warm_route_available() || !ntiles || all_bytes < g_warm_min_bytes) return WarmPlan();
+    if (!warm_route_available() || !ntiles || all_bytes < tuning().warm_min_bytes) return WarmPlan();
     for (size_t i = 0; i < nd; i++)
         if (!warm_narrow(descs[i], true)) return WarmPlan();
     return warm_plan_of(ntiles, all_bytes);
@@ -238,9 +276,10 @@ static WarmPlan warm_plan_for(const zbra_array_desc *descs, size_t nd, uint64_t 
 // warm-up of each chunk.
 static void launch_decode_submission(hipStream_t stream, const DecodePlan *plans, const uint64_t *ts, const uint32_t *tmap, uint32_t nd,
                                      uint64_t first, uint64_t ntiles, uint32_t order, const WarmPlan &wp) {
-    DecodeConfig c = decode_config();
+    const Tuning &t = tuning();
+    DecodeConfig c = t.decode;
     if (!wp.on) {
-        g_decode_fn(c, stream, plans, ts, tmap, nd, first, ntiles, order);
+        t.decode_fn(c, stream, plans, ts, tmap, nd, first, ntiles, order);
         return;
     }
     c.nt = 2;      // plain loads (they hit what the warm-up left), nontemporal stores
@@ -249,14 +288,12 @@ static void launch_decode_submission(hipStream_t stream, const DecodePlan *plans
         const uint64_t n = ntiles - done < wp.tiles_per_chunk ? ntiles - done : wp.tiles_per_chunk;
         const unsigned grid = (unsigned)((n + wp.tiles_per_wg - 1) / wp.tiles_per_wg);
         hipLaunchKernelGGL((warm_tiles_kernel<2048>), dim3(grid), dim3(256), 0, stream, plans, ts, tmap, nd, first + done, n, wp.tiles_per_wg,
-                           g_warm_bits > 31 ? 31u : g_warm_bits);
-        g_decode_fn(c, stream, plans, ts, tmap, nd, first + done, n, order);
+                           t.warm_bits > 31 ? 31u : t.warm_bits);
+        t.decode_fn(c, stream, plans, ts, tmap, nd, first + done, n, order);
     }
 }
 
 constexpr unsigned STREAM_GRID_CAP = 256 * 8;
-
-static int g_enum_reverse = -1;  // -1: by size; 0 / 1 force the order of the enum write pass (tuning)
 
 // Arrays one device submission handles at once: its per-array launches (one workgroup of up to
 // 1024 lanes per array) stay far inside the work-items of a dispatch, and its tables stay small.
@@ -337,7 +374,7 @@ static int decode_batch_dev(DeviceCtx *ctx, const zbra_array_desc *descs, size_t
     }
     const bool all_narrow = route && warm_plan_for(descs, nd, ntiles, all_bytes).on;
     // worth its two extra launches only when the narrow arrays are a fair share of the work (a quarter of the tiles)
-    const bool mixed = !all_narrow && n_narrow && n_bytes >= g_warm_min_bytes && n_tiles * 4 >= ntiles;
+    const bool mixed = !all_narrow && n_narrow && n_bytes >= tuning().warm_min_bytes && n_tiles * 4 >= ntiles;
     const size_t off_ts = align_up(nd * sizeof(zbra_array_desc), 64);
     const size_t off_orig = align_up(off_ts + (nd + 1) * sizeof(uint64_t), 64);       // caller's index of each array (mixed only)
     const size_t host_bytes = off_orig + (mixed ? nd * sizeof(uint32_t) : 0);
@@ -533,7 +570,7 @@ static int encode_batch_dev(DeviceCtx *ctx, const EncodeItem *items, size_t nd, 
     ZBRA_TRY(ctx->lock_scratch_of(stream, &ss));
     std::lock_guard<std::mutex> scratch_guard(ss->mu, std::adopt_lock);
     ZBRA_TRY(DeviceCtx::grow_scratch(ss, scratch_bytes));
-    char *scratch = (char *)ss->mem.ptr;
+    char *enc_mem = (char *)ss->mem.ptr;  // (not `scratch`: that name is the no-allocation entry point's device symbol)
     Slot *s;
     ZBRA_TRY(ctx->acquire(total, &s, host_bytes));
     EncodeJob *h_jobs = (EncodeJob *)s->host;
@@ -551,7 +588,7 @@ static int encode_batch_dev(DeviceCtx *ctx, const EncodeItem *items, size_t nd, 
         j.sel_values = items[i].values; j.sel_n = items[i].n; j.sel_kind = items[i].kind;
         j.seg_cap = seg_cap_of(items[i]);
         if (j.seg_cap) {
-            j.cand = (int64_t *)(scratch + scratch_off);
+            j.cand = (int64_t *)(enc_mem + scratch_off);
             scratch_off += j.seg_cap * CAND_SEGS * sizeof(int64_t);
         }
         if (listed(items[i])) {
@@ -560,7 +597,7 @@ static int encode_batch_dev(DeviceCtx *ctx, const EncodeItem *items, size_t nd, 
             h_list[i_list++] = (uint32_t)i;
             if (is_long(items[i])) {
                 j.lvl_hist = (uint32_t *)((char *)s->dev + off_lvl) + (size_t)i_big * SEL_LEVELS * BINS;
-                j.small = (uint64_t *)(scratch + off_small) + (size_t)i_big * GATHER_SEGS * GATHER_CAP;
+                j.small = (uint64_t *)(enc_mem + off_small) + (size_t)i_big * GATHER_SEGS * GATHER_CAP;
                 i_big++;
             }
         }
@@ -640,7 +677,7 @@ static int encode_batch_dev(DeviceCtx *ctx, const EncodeItem *items, size_t nd, 
                 // at 2^28 rows and 1-4 % faster at 2^27 (pack at width 12: 213 against 221 us,
                 // raw: 350 against 364).  ZBRA_HIP_PACK_XCD=0|1 forces one or the other.
                 // past the work-items of one dispatch the workgroups take several tiles each, in the plain order
-                const uint64_t pack_most = g_launch_limit / THREADS ? g_launch_limit / THREADS : 1;
+                const uint64_t pack_most = launch_limit() / THREADS ? launch_limit() / THREADS : 1;
                 const unsigned gp = grid_for(ntiles, (uint64_t)pack_grid_cap() < pack_most ? pack_grid_cap() : (unsigned)pack_most);
                 static const int pack_xcd_env = [] { const char *e = getenv("ZBRA_HIP_PACK_XCD"); return e ? atoi(e) : -1; }();
                 const bool pack_xcd = pack_xcd_env >= 0 ? pack_xcd_env != 0 : nd > 1;
@@ -941,27 +978,22 @@ using namespace zbra;
 
 extern "C" {
 
-// Tuning hooks (not part of the ABI, not declared in the header).  Not thread-safe.
-// zbra_tuning_set_launch_limit: work-items per dispatch (0 = the hardware's 2^32 - 1).
-// zbra_tuning_set_decode_warm: packed bytes per warmed chunk (0 = off), widest array that takes
-// the warm-up path, smallest submission that does (defaults 64 MiB, 6 bits, 8 MiB).
-// zbra_tuning_set_decode_variant: switches the decode kernel shape at run time so that variants can
-// be timed interleaved in one process.
+// Test and tuning hooks, declared in include/zbra_hip_tuning.h (not part of the product ABI).  Each
+// publishes a new policy snapshot under the writers' mutex; calls already running keep the old one.
 int zbra_tuning_set_decode_warm(uint64_t chunk_bytes, uint32_t max_bits, uint64_t min_bytes) {
-    g_warm_bytes = chunk_bytes;
-    g_warm_bits = max_bits;
-    g_warm_min_bytes = min_bytes;
+    retune([&](Tuning &t) { t.warm_bytes = chunk_bytes; t.warm_bits = max_bits; t.warm_min_bytes = min_bytes; return true; });
     return 0;
 }
-int zbra_tuning_set_enum_reverse(int r) { g_enum_reverse = r; return 0; }
+int zbra_tuning_set_enum_reverse(int r) {
+    retune([&](Tuning &t) { t.enum_reverse = r; return true; });
+    return 0;
+}
 int zbra_tuning_set_launch_limit(uint64_t work_items) {
-    g_launch_limit = work_items && work_items < 0xFFFFFFFFull ? work_items : 0xFFFFFFFFull;
+    retune([&](Tuning &t) { t.launch_limit = work_items && work_items < 0xFFFFFFFFull ? work_items : 0xFFFFFFFFull; return true; });
     return 0;
 }
 int zbra_tuning_set_decode_variant(int tile, int threads, int nt, int direct, int xcd) {
-    (void)decode_config();
-    g_decode_cfg.xcd = xcd;
-    return apply_variant(g_decode_cfg, tile, threads, nt, direct) ? 0 : 1;
+    return retune([&](Tuning &t) { t.decode.xcd = xcd; return apply_variant(t, tile, threads, nt, direct); }) ? 0 : 1;
 }
 
 const char *zbra_hip_version(void) { return "zbra-hip 0.1 (gfx950)"; }
@@ -1203,7 +1235,7 @@ int zbra_hip_enum_rows_dev(const uint32_t *d_tags, size_t n, const uint32_t *var
                 hipLaunchKernelGGL(enum_scan_totals_kernel, dim3(n_variants), dim3(SCAN_CHUNK), 0, stream, nchunks, chunk_base, d_counts);
             }
             hipLaunchKernelGGL(enum_write_kernel, dim3((unsigned)ntiles), dim3(ENUM_THREADS), 0, stream, d_tags, (uint64_t)n, d_vt, n_variants,
-                               ntiles, nchunks, tile_counts, chunk_base, d_variant, d_rank, g_enum_reverse < 0 ? ((uint64_t)n * 4 > ((uint64_t)208 << 20) ? 1u : 0u) : (uint32_t)g_enum_reverse);
+                               ntiles, nchunks, tile_counts, chunk_base, d_variant, d_rank, tuning().enum_reverse < 0 ? ((uint64_t)n * 4 > ((uint64_t)208 << 20) ? 1u : 0u) : (uint32_t)tuning().enum_reverse);
         }
         hipLaunchKernelGGL(enum_report_kernel, dim3(1), dim3(64), 0, stream, d_tags, (uint64_t)n, d_bad, d_result);
         st = hip_status(hipGetLastError());

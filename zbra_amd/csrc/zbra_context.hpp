@@ -3,6 +3,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <mutex>
 #include <vector>
 
@@ -136,32 +137,46 @@ struct DeviceCtx {
     uint64_t scratch_tick = 0;
     int lock_scratch_of(hipStream_t stream, StreamScratch **out) {
         for (;;) {
-            StreamScratch *found = nullptr;
+            StreamScratch *found = nullptr, *victim = nullptr;
+            hipStream_t old_stream = nullptr;
             {
                 std::lock_guard<std::mutex> g(mu);
                 for (StreamScratch *ss : stream_scratch)
                     if (ss->stream == stream) { found = ss; break; }
                 if (!found && stream_scratch.size() >= MAX_STREAM_SCRATCH) {
-                    StreamScratch *victim = nullptr;
-                    for (StreamScratch *ss : stream_scratch)
-                        if (!victim || ss->used < victim->used) victim = ss;
-                    if (victim->mu.try_lock()) {  // nobody is enqueueing with it
-                        const hipError_t e = hipDeviceSynchronize();
-                        if (e != hipSuccess) { victim->mu.unlock(); return hip_status(e); }
-                        if (victim->mem.ptr) (void)hipFree(victim->mem.ptr);
-                        victim->mem = Arena();
+                    // the least recently used buffer that nobody is enqueueing with: idle entries are
+                    // tried in LRU order before the list may grow past its cap
+                    std::vector<StreamScratch *> by_age(stream_scratch);
+                    std::sort(by_age.begin(), by_age.end(), [](const StreamScratch *a, const StreamScratch *b) { return a->used < b->used; });
+                    for (StreamScratch *ss : by_age)
+                        if (ss->mu.try_lock()) { victim = ss; break; }
+                    if (victim) {
+                        // re-labelled under `mu` (so that no other thread finds it under its old
+                        // stream) and handed over with its own mutex held; the wait for the old
+                        // stream's work and the free happen below, without `mu`
+                        old_stream = victim->stream;
                         victim->stream = stream;
                         victim->used = ++scratch_tick;
-                        *out = victim;
-                        return ZBRA_OK;
                     }
                 }
-                if (!found) {
+                if (!found && !victim) {  // below the cap, or every buffer is in somebody's hands
                     found = new StreamScratch();
                     found->stream = stream;
                     stream_scratch.push_back(found);
                 }
-                found->used = ++scratch_tick;
+                if (found) found->used = ++scratch_tick;
+            }
+            if (victim) {
+                // kernels enqueued on the old stream may still use the buffer: only that stream is
+                // waited for (a stream the caller has destroyed in the meantime reports an error,
+                // and then the device is waited for instead), and nobody else's acquire()/release() waits with us
+                hipError_t e = hipStreamSynchronize(old_stream);
+                if (e != hipSuccess) { (void)hipGetLastError(); e = hipDeviceSynchronize(); }
+                if (e != hipSuccess) { victim->mu.unlock(); return hip_status(e); }
+                if (victim->mem.ptr) (void)hipFree(victim->mem.ptr);
+                victim->mem = Arena();
+                *out = victim;
+                return ZBRA_OK;
             }
             // not under `mu`: whoever holds the buffer's mutex takes `mu` for its workspace slot
             found->mu.lock();

@@ -25,11 +25,36 @@ def first_row(rank: int, rows_per_rank: int) -> int:
 
 
 def job_totals(elapsed_s: float, units: float, device="cpu"):
-    """(max elapsed over ranks, sum of units over ranks); identity when not distributed."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    """(max elapsed over ranks, sum of units over ranks); identity when no process group exists.
+    A group of one rank still runs the two all-reduces: that is how a single GPU rehearses the
+    collective path of the many-GPU job."""
+    if not (dist.is_available() and dist.is_initialized()):
         return elapsed_s, units
     t = torch.tensor([elapsed_s], dtype=torch.float64, device=device)
     u = torch.tensor([units], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dist.all_reduce(u, op=dist.ReduceOp.SUM)
     return float(t.item()), float(u.item())
+
+
+def gather_ranks(entry):
+    """Every rank's `entry` (any picklable object) in rank order, on every rank; [entry] when no
+    process group exists."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return [entry]
+    got = [None] * dist.get_world_size()
+    dist.all_gather_object(got, entry)
+    return got
+
+
+def ranks_seen() -> int:
+    """Size of the process group as the collective library reports it (1 without a group)."""
+    return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+
+
+def shared_devices(devices):
+    """Device identities that more than one rank reports, sorted: a one-rank-per-GPU job must have none."""
+    seen, twice = set(), set()
+    for d in devices:
+        (twice if d in seen else seen).add(d)
+    return sorted(twice)
