@@ -156,6 +156,15 @@ namespace binary {
 static const char MAGIC_NUMBER[17] = "||_ZBRA||00001||";  // binary.rs:17
 static const char COMPRESSION_NONE[] = "{\"binary_data\":\"None\",\"strings\":\"None\"}";  // serde JSON of CompressionConfig{None, None}
 
+// Does the CompressionConfig JSON (compression.rs:13-41, serde's externally tagged form) say
+// CompressionAlgorithm::None for `key` ("binary_data" or "strings")?  Whitespace is ignored.
+inline bool config_stores_plain(const std::string &json, const char *key) {
+    std::string compact;
+    for (char ch : json)
+        if (ch != ' ' && ch != '\t' && ch != '\n' && ch != '\r') compact.push_back(ch);
+    return compact.find(std::string("\"") + key + "\":\"None\"") != std::string::npos;
+}
+
 struct Block {  // binary.rs:63-66
     uint32_t row_count = 0;
     striped::TablePtr table;
@@ -232,9 +241,12 @@ static_assert(sizeof(size_t) == 8 && sizeof(double) == 8, "lengths and f64 bit p
 // arrays are already decoded, in file order.
 class TreeReader {
 public:
-    TreeReader(const uint8_t *image, size_t len, std::vector<DecodedArray> &decoded) : r_(image, len), decoded_(decoded) {}
+    // binary_data_stored / strings_stored: the image's config says CompressionAlgorithm::None for that kind of blob
+    TreeReader(const uint8_t *image, size_t len, std::vector<DecodedArray> &decoded, bool binary_data_stored = true, bool strings_stored = true)
+        : r_(image, len), decoded_(decoded), stored_{binary_data_stored, strings_stored} {}
     size_t &pos() { return r_.pos; }
     bool failed = false;
+    bool unsupported_blob = false;  // a byte blob under a zstd config was met: its bytes are still compressed
 
     uint8_t u8() { uint8_t v = 0; if (!r_.read_exact(&v, 1)) failed = true; return v; }
     uint32_t u32() { uint32_t v = 0; if (!read_u32(r_, &v)) failed = true; return v; }
@@ -244,11 +256,15 @@ public:
         if (s.size() != n || !r_.read_exact(&s[0], n)) failed = true;
         return s;
     }
-    std::vector<uint8_t> zblob() {  // read_sized_byte_array_compressed with CompressionAlgorithm::None :690-699
+    // read_sized_byte_array_compressed :690-699.  Under CompressionAlgorithm::None the stored bytes
+    // are the blob; under Zstd they would have to go through decompress_binary (compression.rs:251-268),
+    // the byte codec this library does not carry: such a blob is reported, never handed back as data.
+    std::vector<uint8_t> zblob(int which) {
         u32();
         const uint32_t n = u32();
         std::vector<uint8_t> d(r_.len - r_.pos >= n ? n : 0);
         if (d.size() != n || !r_.read_exact(d.data(), n)) failed = true;
+        if (!stored_[which]) unsupported_blob = true;  // even an empty blob is a zstd frame there, not zero bytes
         return d;
     }
     striped::Encoding encoding() { striped::Encoding e; e.family = u8(); e.value = u8(); return e; }
@@ -283,7 +299,7 @@ public:
                 break;
             case Column::Double: c->default_ = (striped::Default)u8(); c->doubles = i64_array_as<double>(); break;
             case Column::Binary:
-                c->default_ = (striped::Default)u8(); c->encoding = encoding(); c->lengths = i64_array_as<size_t>(); c->data = zblob();
+                c->default_ = (striped::Default)u8(); c->encoding = encoding(); c->lengths = i64_array_as<size_t>(); c->data = zblob(1);
                 break;
             case Column::Array: c->default_ = (striped::Default)u8(); c->lengths = i64_array_as<size_t>(); c->inner = column(); break;
             case Column::Struct: {
@@ -314,7 +330,7 @@ public:
         t->kind = (Table::Kind)tag;
         t->default_ = (striped::Default)u8();
         switch (t->kind) {
-            case Table::Binary: t->encoding = encoding(); t->data = zblob(); break;
+            case Table::Binary: t->encoding = encoding(); t->data = zblob(0); break;
             case Table::Array: t->column = column(); break;
             case Table::Map: t->column = column(); t->value_column = column(); break;
         }
@@ -325,6 +341,7 @@ private:
     Reader r_;
     std::vector<DecodedArray> &decoded_;
     size_t next_ = 0;
+    bool stored_[2];
 };
 
 // binary::BinaryFile (binary.rs:56-59) with the header's two JSON documents kept as text: the schema
@@ -336,9 +353,7 @@ struct BinaryFile {
 
     // BinaryFile::to_bytes / write_to                                     binary.rs:96-130
     Result<std::vector<uint8_t>> to_bytes() const {
-        const bool bd = compression_json.find("\"binary_data\":\"None\"") != std::string::npos;
-        const bool st = compression_json.find("\"strings\":\"None\"") != std::string::npos;
-        TreeWriter w(bd, st);
+        TreeWriter w(config_stores_plain(compression_json, "binary_data"), config_stores_plain(compression_json, "strings"));
         w.bytes(MAGIC_NUMBER, 16);
         w.sized(schema_json.data(), schema_json.size());
         w.sized(compression_json.data(), compression_json.size());
@@ -372,7 +387,7 @@ struct BinaryFile {
         BinaryFile f;
         f.schema_json.assign((const char *)image + df.info.schema_offset, df.info.schema_len);
         f.compression_json.assign((const char *)image + df.info.compression_offset, df.info.compression_len);
-        TreeReader r(image, len, df.arrays);
+        TreeReader r(image, len, df.arrays, config_stores_plain(f.compression_json, "binary_data"), config_stores_plain(f.compression_json, "strings"));
         r.pos() = df.info.blocks_offset;
         const uint32_t n = r.u32();
         for (uint32_t i = 0; i < n && !r.failed; i++) {  // Block::read_from :195-199
@@ -382,6 +397,8 @@ struct BinaryFile {
             f.blocks.push_back(std::move(b));
         }
         if (r.failed) return BinaryError{BinaryError::DecompressionError, "image changed between the index walk and the tree walk", ZBRA_ERR_FORMAT};
+        if (r.unsupported_blob)  // binary.rs:690-699 would call decompress_binary here
+            return BinaryError{BinaryError::DecompressionError, "byte blobs compressed with zstd are not supported (CompressionAlgorithm::None only)", ZBRA_ERR_INVALID_ARG};
         return f;
     }
     static Result<BinaryFile> from_bytes(const std::vector<uint8_t> &image) { return from_bytes(image.data(), image.size()); }

@@ -290,8 +290,9 @@ int zbra_hip_decode_batch(const zbra_array_desc *descs, size_t nd, int *statuses
  * .cap ignored) become frames `u32 count | u32 clen | E` back to back in the HOST buffer `out`,
  * which is what Column::write_to emits for each of them (binary.rs:293-347 through :639-669).
  * offsets receives nd + 1 entries; statuses (may be NULL) one zbra_status per array; the return
- * value is the first non-OK status.  Uploads, the batched encode and the copy back are pipelined
- * over rounds of arrays. */
+ * value is the first non-OK status.  The arrays go through in rounds on two alternating streams:
+ * while one round's values are uploaded and encoded, the previous round's frames are copied back
+ * (by a second host thread that lives for the call), so both directions of the link are busy. */
 int zbra_hip_encode_frames(const zbra_encode_desc *descs, size_t nd, uint8_t *out, size_t cap, uint64_t *offsets,
                            int *statuses);
 

@@ -21,14 +21,6 @@ sys.path.insert(0, ROOT)
 import numpy as np
 
 
-def sm(seed, i):
-    z = (np.uint64(seed) + (i + np.uint64(1)) * np.uint64(0x9E3779B97F4A7C15))
-    z ^= z >> np.uint64(30); z *= np.uint64(0xBF58476D1CE4E5B9)
-    z ^= z >> np.uint64(27); z *= np.uint64(0x94D049BB133111EB)
-    z ^= z >> np.uint64(31)
-    return z
-
-
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--blocks", type=int, default=24)
@@ -50,17 +42,8 @@ def main():
         else:
             dist.init_process_group(backend=backend)
     n = 1 << args.rows_log2
-    blocks = []
-    with np.errstate(over="ignore"):
-        for b in range(rank * args.blocks, (rank + 1) * args.blocks):  # file `rank` holds these rows of the table
-            i = np.arange(b * n, (b + 1) * n, dtype=np.uint64)
-            entity = (1000 + (i // np.uint64(64)) % np.uint64(50000)).astype(np.int64)
-            attribute = (sm(0x5EED0005, i) % np.uint64(200)).astype(np.int64)
-            t_ms = (1_700_000_000_000 + i.astype(np.int64) * 1000)
-            value = (sm(0x5EED1005, i) % np.uint64(4000)).astype(np.int64)
-            blocks.append(zb.Block(n, zb.ArrayTable(zb.Struct([
-                ("attribute_id", zb.Int(attribute)), ("entity_id", zb.Int(entity)),
-                ("time", zb.Int(t_ms, "TimeMilliseconds")), ("value", zb.Int(value))]))))
+    from zbra_amd import workloads
+    blocks = workloads.file_blocks(rank * args.blocks, args.blocks, n)  # file `rank` holds these rows of the table
     t0 = time.perf_counter()
     img = zb.BinaryFile("{}", blocks).to_bytes()
     t_write = time.perf_counter() - t0

@@ -27,8 +27,6 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import numpy as np
 
-from bench_file import sm  # noqa: E402  (same directory)
-
 
 def main():
     ap = argparse.ArgumentParser()
@@ -46,18 +44,9 @@ def main():
     dev = torch.device("cuda", 0)
     torch.cuda.set_device(dev)
     n = 1 << args.rows_log2
-    cols, blocks = [], []
-    with np.errstate(over="ignore"):
-        for b in range(args.blocks):
-            i = np.arange(b * n, (b + 1) * n, dtype=np.uint64)
-            entity = (1000 + (i // np.uint64(64)) % np.uint64(50000)).astype(np.int64)
-            attribute = (sm(0x5EED0005, i) % np.uint64(200)).astype(np.int64)
-            t_ms = (1_700_000_000_000 + i.astype(np.int64) * 1000)
-            value = (sm(0x5EED1005, i) % np.uint64(4000)).astype(np.int64)
-            cols += [attribute, entity, t_ms, value]
-            blocks.append(zb.Block(n, zb.ArrayTable(zb.Struct([
-                ("attribute_id", zb.Int(attribute)), ("entity_id", zb.Int(entity)),
-                ("time", zb.Int(t_ms, "TimeMilliseconds")), ("value", zb.Int(value))]))))
+    from zbra_amd import workloads
+    blocks = workloads.file_blocks(0, args.blocks, n)
+    cols = [dict(b.table.column.fields)[name].values for b in blocks for name in workloads.FILE_COLUMNS]
     base = np.frombuffer(zb.BinaryFile("{}", blocks).to_bytes(), dtype=np.uint8)
     binfo, barrays = zb.file_index(base)
     per = 4 * args.blocks                               # int arrays per group of Blocks

@@ -141,9 +141,44 @@ int main(int argc, char **argv) {
     zb.row_count = 3;
     zb.table = Table::array(Column::int_({1, 2, 3}));
     z.blocks.push_back(zb);
-    CHECK(z.to_bytes().is_ok());
+    auto zi = z.to_bytes();
+    CHECK(zi.is_ok());
+    if (zi.is_ok()) {  // ... and reads back under that config: it holds no blob
+        auto zr = binary::BinaryFile::from_bytes(zi.value());
+        CHECK(zr.is_ok() && zr.value().compression_json == z.compression_json && striped::equal(zr.value().blocks[0].table, zb.table));
+    }
     z.blocks[0].table = Table::array(Column::binary({2}, {'h', 'i'}));
     CHECK(z.to_bytes().is_err());
+    // The read side of the same rule: an image whose config says Zstd for its blobs, as the reference
+    // writes by default (compression.rs:34-41), holds compressed bytes where the blob is
+    // (binary.rs:690-699 -> decompress_binary).  They must not come back as the column's data.
+    // The image is the one the None config writes, with the config document swapped.
+    binary::BinaryFile plain = z;
+    plain.compression_json = binary::COMPRESSION_NONE;
+    auto pi = plain.to_bytes();
+    CHECK(pi.is_ok());
+    if (pi.is_ok()) {
+        auto pr = binary::BinaryFile::from_bytes(pi.value());
+        CHECK(pr.is_ok() && striped::equal(pr.value().blocks[0].table, plain.blocks[0].table));
+        zbra_file_info info;
+        CHECK(zbra_hip_file_index(pi.value().data(), pi.value().size(), nullptr, 0, &info, nullptr) == ZBRA_OK);
+        const std::vector<uint8_t> &src = pi.value();
+        std::vector<uint8_t> swapped(src.begin(), src.begin() + (long)info.compression_offset - 8);
+        const uint32_t zl = (uint32_t)z.compression_json.size();
+        for (int rep = 0; rep < 2; rep++)
+            for (int k = 0; k < 4; k++) swapped.push_back((uint8_t)(zl >> (8 * k)));
+        swapped.insert(swapped.end(), z.compression_json.begin(), z.compression_json.end());
+        swapped.insert(swapped.end(), src.begin() + (long)(info.compression_offset + info.compression_len), src.end());
+        auto sr = binary::BinaryFile::from_bytes(swapped);
+        CHECK(sr.is_err());
+        if (sr.is_err()) CHECK(sr.error().kind == BinaryError::DecompressionError);
+        // strings only: binary_data may stay Zstd when the tree holds no Table::Binary
+        binary::BinaryFile half = plain;
+        half.compression_json = "{ \"binary_data\": {\"Zstd\":{\"level\":3}}, \"strings\": \"None\" }";
+        auto hi = half.to_bytes();
+        CHECK(hi.is_ok());
+        if (hi.is_ok()) CHECK(binary::BinaryFile::from_bytes(hi.value()).is_ok());
+    }
     std::printf("%d checks, %d failures\n", checks, failures);
     return failures ? 1 : 0;
 }

@@ -126,3 +126,62 @@ def test_batch_encode_medians_at_scale(env):
         assert [r.status for r in rs] == [0] * len(cols)
         assert [r.midpoint for r in rs] == want, rep
         assert all((r.width in (1, 2)) if i % 2 == 0 else r.width == 26 for i, r in enumerate(rs))
+
+
+def test_config5_file_blocks_reduced(env):
+    """The full-file configuration's own shape (Blocks of 4 Int columns: attribute id, entity id,
+    time, value) at 3 Blocks of 2^15 rows: the image written through the C ABI
+    (zbra_hip_encode_frames behind BinaryFile.to_bytes) equals the oracle-built image byte for
+    byte, and zbra_hip_file_index + zbra_hip_file_decode give back the generated columns, which
+    are regenerated here from the formulas and not taken from the tree."""
+    import ctypes as C
+    torch, device, workloads, oc, on, L = env
+    from zbra_amd import binary as zb
+
+    class OracleCodec:
+        compress_int_array = staticmethod(oc.compress_int_array)
+
+    rows, first_block, n_blocks = 1 << 15, 5, 3
+    blocks = workloads.file_blocks(first_block, n_blocks, rows)
+    f = zb.BinaryFile('{"Array":{"default":"Allow"}}', blocks)
+    img = f.to_bytes()
+    assert img == f.to_bytes(OracleCodec)
+    info, arrays = zb.file_index(img)
+    assert info.block_count == n_blocks and info.n_arrays == 4 * n_blocks and info.total_values == 4 * n_blocks * rows
+    # the frames alone, through the C ABI with the arrays as the caller holds them: the bytes between
+    # each frame's start and end in the image
+    want_cols = []
+    for b in range(first_block, first_block + n_blocks):
+        i = np.arange(b * rows, (b + 1) * rows, dtype=np.uint64)
+        want_cols += [(on.sm(0x5EED0005, i) % np.uint64(200)).astype(np.int64),
+                      (1000 + (i // np.uint64(64)) % np.uint64(50000)).astype(np.int64),
+                      1_700_000_000_000 + i.astype(np.int64) * 1000,
+                      (on.sm(0x5EED1005, i) % np.uint64(4000)).astype(np.int64)]
+    na = len(want_cols)
+    edescs = device.make_encode_descs([(c.ctypes.data, c.size, 0, 0, L.ELEM_I64) for c in want_cols])
+    cap = sum(8 + device.encode_bound(c.size) for c in want_cols)
+    frames = np.zeros(cap, dtype=np.uint8)
+    offs = np.zeros(na + 1, dtype=np.uint64)
+    st = L.lib.zbra_hip_encode_frames(edescs, na, frames.ctypes.data_as(C.c_void_p), cap, offs.ctypes.data_as(C.POINTER(C.c_uint64)), None)
+    assert st == 0
+    widths = []
+    for k in range(na):
+        a = arrays[k]
+        assert a.role == 0 and a.kind == L.ELEM_I64 and a.count == rows and a.block == k // 4
+        got = frames[int(offs[k]):int(offs[k + 1])].tobytes()
+        assert got == img[a.offset - 8:a.offset + a.len], k
+        assert got[8:] == oc.compress_int_array(want_cols[k]), k
+        widths.append(got[8 + 12])
+    # attribute id <= 8 bits, entity id clustered, time monotone (1 s steps over 2^15 rows), value <= 12 bits
+    assert widths[0] == 8 and widths[3] == 12 and widths[2] == 25 and widths[1] <= 10, widths
+    outs = [np.full(rows, -1, dtype=np.int64) for _ in range(na)]
+    ptrs = (C.c_void_p * na)(*[o.ctypes.data for o in outs])
+    statuses = (C.c_int * na)()
+    buf = np.frombuffer(img, dtype=np.uint8)
+    assert L.lib.zbra_hip_file_decode(buf.ctypes.data_as(C.c_void_p), buf.size, arrays, na, ptrs, statuses) == 0
+    assert list(statuses) == [0] * na
+    for k in range(na):
+        assert np.array_equal(outs[k], want_cols[k]), k
+    back = zb.BinaryFile.from_bytes(img)
+    assert [b.row_count for b in back.blocks] == [rows] * n_blocks
+    assert np.array_equal(dict(back.blocks[2].table.column.fields)["time"].values, want_cols[10])

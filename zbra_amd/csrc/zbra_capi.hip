@@ -5,9 +5,11 @@
 #include <cstdio>
 #include <cstdlib>
 #include <atomic>
+#include <condition_variable>
 #include <cstring>
 #include <map>
 #include <mutex>
+#include <thread>
 #include <vector>
 
 #include "zbra_context.hpp"
@@ -1300,67 +1302,169 @@ int zbra_hip_encode_frames(const zbra_encode_desc *descs, size_t nd, uint8_t *ou
     DeviceCtx *ctx;
     ZBRA_TRY(current_ctx(&ctx));
     std::lock_guard<std::mutex> g(ctx->host_mu);
-    // Rounds of consecutive arrays: bounded input bytes and array count per submission.
-    constexpr size_t ROUND_IN = (size_t)2 << 30, ROUND_ARRAYS = 4096;
+    ZBRA_TRY(ctx->ensure_enc_lanes());
+    // Rounds of consecutive arrays: bounded input bytes and array count per submission.  Rounds
+    // alternate between two lanes (stream + device buffers).  This thread produces: it uploads a
+    // round's values (pageable memory -> pinned ring -> device) and enqueues the batched encode with
+    // device-side framing.  A second thread consumes, round by round in order: it waits for the
+    // round's result words, copies the frames back behind the previous round's and fills in offsets
+    // and statuses.  Round r + 1 therefore goes up while round r's frames come down: both directions
+    // of the link work at once (one round after the other, 164 GB of values took 4.28 s where the
+    // upload alone needs 2.9 s).  A job of one round runs both halves on this thread.
+    constexpr size_t ROUND_ARRAYS = 4096;
     auto in_bytes = [&](size_t i) { return (size_t)((descs[i].n * (descs[i].kind == ZBRA_ELEM_I64 ? 8 : 4) + 15) / 16 * 16); };
+    size_t all_in = 0;
+    for (size_t i = 0; i < nd; i++) all_in += in_bytes(i);
+    // a quarter of the job per round, so that even a job of a few hundred MiB overlaps its two directions
+    const size_t ROUND_IN = all_in / 4 < ((size_t)64 << 20) ? (size_t)64 << 20 : all_in / 4 > ((size_t)512 << 20) ? (size_t)512 << 20 : all_in / 4;
+    struct Round { size_t r0, r1, total_in, bound, room, off_res, tmp_bytes; };
+    std::vector<Round> rounds;
+    for (size_t r0 = 0; r0 < nd;) {
+        Round rd{r0, r0, 0, 0, 0, 0, 0};
+        while (rd.r1 < nd && rd.r1 - r0 < ROUND_ARRAYS && (rd.r1 == r0 || rd.total_in + in_bytes(rd.r1) <= ROUND_IN)) {
+            rd.total_in += in_bytes(rd.r1);
+            rd.bound += 8 + zbra_hip_encode_bound(descs[rd.r1].n);
+            rd.r1++;
+        }
+        rd.off_res = align_up((rd.r1 - r0 + 1) * sizeof(uint64_t), 64);
+        rd.tmp_bytes = rd.off_res + (rd.r1 - r0) * sizeof(zbra_dev_result);
+        rounds.push_back(rd);
+        r0 = rd.r1;
+    }
+    // shared between the two threads, under `mu`
+    std::mutex mu;
+    std::condition_variable cv;
+    size_t written = 0, produced = 0, consumed = 0, outstanding_bound = 0;
+    int first_err = ZBRA_OK, failure = ZBRA_OK;  // first_err: an array's status; failure: the call cannot go on
+    bool full = false, stop = false;             // full: a frame did not fit
+
     std::vector<EncodeItem> items;
     std::vector<HostPipe::Segment> segs;
-    size_t written = 0;
-    int first_err = ZBRA_OK;
-    bool full = false;  // a frame did not fit
-    for (size_t r0 = 0; r0 < nd;) {
-        if (full) {
-            // frames are laid out in order: after the first that did not fit nothing more is
-            // written, and every later array is reported as an empty range at the end
-            for (size_t i = r0; i < nd; i++) {
-                offsets[i + 1] = written;
-                if (statuses) statuses[i] = ZBRA_ERR_CAPACITY;
-            }
-            break;
-        }
-        size_t r1 = r0, total_in = 0, bound = 0;
-        while (r1 < nd && r1 - r0 < ROUND_ARRAYS && (r1 == r0 || total_in + in_bytes(r1) <= ROUND_IN)) {
-            total_in += in_bytes(r1);
-            bound += 8 + zbra_hip_encode_bound(descs[r1].n);
-            r1++;
-        }
-        const size_t nr = r1 - r0;
-        const size_t room = cap - written < bound ? cap - written : bound;  // what this round may fill
-        const size_t off_res = align_up((nr + 1) * sizeof(uint64_t), 64);
-        const size_t tmp_bytes = off_res + nr * sizeof(zbra_dev_result);
-        ZBRA_TRY(DeviceCtx::grow_dev(ctx->dev_in, total_in + 16));
-        ZBRA_TRY(DeviceCtx::grow_dev(ctx->dev_out, room + 16));
-        ZBRA_TRY(DeviceCtx::grow_dev(ctx->dev_tmp, tmp_bytes));
-        ZBRA_TRY(DeviceCtx::grow_pinned(ctx->pin_res, tmp_bytes));
+    auto produce = [&](size_t k) -> int {  // upload + encode of round k on its lane (which is free)
+        Round &rd = rounds[k];
+        EncodeLane &lane = ctx->enc_lanes[k & 1];
+        const size_t nr = rd.r1 - rd.r0;
+        ZBRA_TRY(DeviceCtx::grow_dev(lane.in, rd.total_in + 16));
+        ZBRA_TRY(DeviceCtx::grow_dev(lane.out, rd.room + 16));
+        ZBRA_TRY(DeviceCtx::grow_dev(lane.tmp, rd.tmp_bytes));
+        ZBRA_TRY(DeviceCtx::grow_pinned(lane.pin, rd.tmp_bytes));
         items.resize(nr);
         segs.clear();
         size_t o = 0;
         for (size_t i = 0; i < nr; i++) {  // the round's arrays go up as one stream, each at a 16-B aligned offset
-            const zbra_encode_desc &d = descs[r0 + i];
+            const zbra_encode_desc &d = descs[rd.r0 + i];
             if (d.n) segs.push_back({o, const_cast<void *>(d.values), (size_t)d.n * (d.kind == ZBRA_ELEM_I64 ? 8 : 4)});
-            items[i] = EncodeItem{(char *)ctx->dev_in.ptr + o, d.n, d.kind, nullptr, 0};
-            o += in_bytes(r0 + i);
+            items[i] = EncodeItem{(char *)lane.in.ptr + o, d.n, d.kind, nullptr, 0};
+            o += in_bytes(rd.r0 + i);
         }
-        ZBRA_TRY(ctx->pipe.to_device_segments(segs.data(), segs.size(), ctx->dev_in.ptr, total_in, ctx->stream));
+        ZBRA_TRY(ctx->pipe_up.to_device_segments(segs.data(), segs.size(), lane.in.ptr, rd.total_in, lane.stream));
         FrameTarget ft;
-        ft.out = (uint8_t *)ctx->dev_out.ptr; ft.cap = room; ft.offsets = (uint64_t *)ctx->dev_tmp.ptr;
-        ZBRA_TRY(encode_batch_dev(ctx, items.data(), nr, (zbra_dev_result *)((char *)ctx->dev_tmp.ptr + off_res), ctx->stream,
-                                  ENCODE_FULL, &ft));
-        ZBRA_HIP_TRY(hipMemcpyAsync(ctx->pin_res.ptr, ctx->dev_tmp.ptr, tmp_bytes, hipMemcpyDeviceToHost, ctx->stream));
-        ZBRA_HIP_TRY(hipStreamSynchronize(ctx->stream));
-        const uint64_t *h_off = (const uint64_t *)ctx->pin_res.ptr;
-        const zbra_dev_result *h_res = (const zbra_dev_result *)((const char *)ctx->pin_res.ptr + off_res);
+        ft.out = (uint8_t *)lane.out.ptr; ft.cap = rd.room; ft.offsets = (uint64_t *)lane.tmp.ptr;
+        ZBRA_TRY(encode_batch_dev(ctx, items.data(), nr, (zbra_dev_result *)((char *)lane.tmp.ptr + rd.off_res), lane.stream, ENCODE_FULL, &ft));
+        ZBRA_HIP_TRY(hipMemcpyAsync(lane.pin.ptr, lane.tmp.ptr, rd.tmp_bytes, hipMemcpyDeviceToHost, lane.stream));
+        return ZBRA_OK;
+    };
+    auto consume = [&](size_t k) -> int {  // frames of round k back to the caller, behind round k - 1's
+        const Round &rd = rounds[k];
+        EncodeLane &lane = ctx->enc_lanes[k & 1];
+        const size_t nr = rd.r1 - rd.r0;
+        ZBRA_HIP_TRY(hipStreamSynchronize(lane.stream));
+        const uint64_t *h_off = (const uint64_t *)lane.pin.ptr;
+        const zbra_dev_result *h_res = (const zbra_dev_result *)((const char *)lane.pin.ptr + rd.off_res);
         const size_t laid_out = (size_t)h_off[nr];
-        ZBRA_TRY(ctx->pipe.to_host(out + written, ctx->dev_out.ptr, laid_out, ctx->stream));
+        size_t at;
+        { std::lock_guard<std::mutex> l(mu); at = written; }
+        ZBRA_TRY(ctx->pipe.to_host(out + at, lane.out.ptr, laid_out, lane.stream));
+        int err = ZBRA_OK;
+        bool over = false;
         for (size_t i = 0; i < nr; i++) {
-            offsets[r0 + i] = written + h_off[i];
-            if (statuses) statuses[r0 + i] = (int)h_res[i].status;
-            if (h_res[i].status != ZBRA_OK && first_err == ZBRA_OK) first_err = (int)h_res[i].status;
-            if (h_res[i].status == ZBRA_ERR_CAPACITY) full = true;
+            offsets[rd.r0 + i] = at + h_off[i];
+            if (statuses) statuses[rd.r0 + i] = (int)h_res[i].status;
+            if (h_res[i].status != ZBRA_OK && err == ZBRA_OK) err = (int)h_res[i].status;
+            if (h_res[i].status == ZBRA_ERR_CAPACITY) over = true;
         }
-        written += laid_out;
-        offsets[r1] = written;
-        r0 = r1;
+        offsets[rd.r1] = at + laid_out;
+        std::lock_guard<std::mutex> l(mu);
+        written = at + laid_out;
+        if (first_err == ZBRA_OK) first_err = err;
+        full = full || over;
+        return ZBRA_OK;
+    };
+
+    const bool threaded = rounds.size() > 1;
+    std::thread consumer;
+    if (threaded)
+        consumer = std::thread([&] {
+            if (hipSetDevice(ctx->device) != hipSuccess) {
+                std::lock_guard<std::mutex> l(mu);
+                failure = ZBRA_ERR_NO_DEVICE; consumed = rounds.size(); cv.notify_all();
+                return;
+            }
+            for (size_t k = 0; k < rounds.size(); k++) {
+                {
+                    std::unique_lock<std::mutex> l(mu);
+                    cv.wait(l, [&] { return produced > k || stop; });
+                    if (produced <= k) return;  // stopped before this round was produced
+                }
+                const int st = consume(k);
+                std::lock_guard<std::mutex> l(mu);
+                consumed = k + 1;
+                outstanding_bound -= rounds[k].bound;
+                if (st != ZBRA_OK && failure == ZBRA_OK) failure = st;
+                cv.notify_all();
+                if (failure != ZBRA_OK) return;
+            }
+        });
+    size_t k = 0;
+    int st = ZBRA_OK;
+    for (; k < rounds.size() && st == ZBRA_OK; k++) {
+        Round &rd = rounds[k];
+        {
+            std::unique_lock<std::mutex> l(mu);
+            // the lane is free once round k - 2 has been consumed
+            cv.wait(l, [&] { return failure != ZBRA_OK || k < 2 || consumed + 2 > k; });
+            // Room for this round's frames.  While the caller's buffer surely holds every round in
+            // flight at its bound plus this one, the round may run ahead; otherwise the rounds before
+            // it are waited for, so that what is left is known exactly (and whether a frame already
+            // did not fit: frames are laid out in order, nothing is written behind such a frame).
+            if (failure == ZBRA_OK && cap - written - (cap - written < outstanding_bound ? cap - written : outstanding_bound) < rd.bound)
+                cv.wait(l, [&] { return failure != ZBRA_OK || consumed == k; });
+            if (failure != ZBRA_OK) { st = failure; break; }
+            if (full) break;
+            rd.room = cap - written - outstanding_bound < rd.bound ? cap - written - outstanding_bound : rd.bound;
+            outstanding_bound += rd.bound;
+        }
+        st = produce(k);
+        if (st == ZBRA_OK) {
+            if (threaded) {
+                std::lock_guard<std::mutex> l(mu);
+                produced = k + 1;
+                cv.notify_all();
+            } else {
+                st = consume(k);
+                produced = consumed = k + 1;
+                outstanding_bound -= rd.bound;
+            }
+        }
+    }
+    if (threaded) {
+        {
+            std::lock_guard<std::mutex> l(mu);
+            stop = true;  // the consumer finishes what was produced, then leaves
+            cv.notify_all();
+        }
+        consumer.join();
+    }
+    if (st == ZBRA_OK) st = failure;
+    // whatever happened, nothing of this call may still run on the lanes when they are reused
+    for (EncodeLane &l : ctx->enc_lanes) (void)hipStreamSynchronize(l.stream);
+    if (st != ZBRA_OK) return st;
+    if (consumed < rounds.size()) {
+        // a frame did not fit: every later array is reported as an empty range at the end
+        for (size_t i = rounds[consumed].r0; i < nd; i++) {
+            offsets[i + 1] = written;
+            if (statuses) statuses[i] = ZBRA_ERR_CAPACITY;
+        }
     }
     return first_err;
 }

@@ -56,6 +56,14 @@ struct FileLane {
     Arena img, res;
 };
 
+// One of the two alternating lanes of the host write path (zbra_hip_encode_frames): a stream and
+// the buffers of the round of arrays in flight on it: values in, frames out, offsets + result words
+// and their pinned twin.
+struct EncodeLane {
+    hipStream_t stream = nullptr;
+    Arena in, out, tmp, pin;
+};
+
 // Device-only memory that the kernels of ONE stream's calls pass through in stream order (the
 // candidate lists of an encode): one buffer per stream serves every call on it, where a buffer per
 // call in flight meant a fresh multi-GiB allocation whenever a caller ran ahead of the device.
@@ -71,6 +79,12 @@ struct DeviceCtx {
     FileLane file_lanes[2];
     int ensure_file_lanes() {
         for (FileLane &l : file_lanes)
+            if (!l.stream) ZBRA_HIP_TRY(hipStreamCreateWithFlags(&l.stream, hipStreamNonBlocking));
+        return ZBRA_OK;
+    }
+    EncodeLane enc_lanes[2];
+    int ensure_enc_lanes() {
+        for (EncodeLane &l : enc_lanes)
             if (!l.stream) ZBRA_HIP_TRY(hipStreamCreateWithFlags(&l.stream, hipStreamNonBlocking));
         return ZBRA_OK;
     }

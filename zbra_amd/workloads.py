@@ -114,3 +114,50 @@ def enum_block(block: int, rows: int, device):
         col_b = 1640995200000 + (block * rows + i) * 1000
         variants.append((tag, col_a, col_b))
     return tags, variants
+
+
+# ---- the full-file configuration: host-side generator (a .zbra file starts in host memory) ------
+
+def sm_np(seed: int, idx):
+    """splitmix64 of a numpy uint64 index array: the same values as sm() above."""
+    import numpy as np
+    with np.errstate(over="ignore"):
+        z = np.uint64(seed) + (idx.astype(np.uint64) + np.uint64(1)) * np.uint64(0x9E3779B97F4A7C15)
+        z ^= z >> np.uint64(30)
+        z *= np.uint64(0xBF58476D1CE4E5B9)
+        z ^= z >> np.uint64(27)
+        z *= np.uint64(0x94D049BB133111EB)
+        z ^= z >> np.uint64(31)
+    return z
+
+
+FILE_COLUMNS = ("attribute_id", "entity_id", "time", "value")  # struct keys in the order the reference CLI emits them (alphabetical)
+
+
+def file_block_columns(block: int, rows: int):
+    """The four Int columns of Block `block` of the full-file configuration's table (rows
+    [block*rows, (block+1)*rows) of it), as int64 numpy arrays keyed by FILE_COLUMNS:
+    entity_id clustered (runs of 64 equal ids out of 50000), attribute_id small range (< 200, at
+    most 8 bits), time milliseconds, monotone with 1 s steps, value < 4000 (at most 12 bits)."""
+    import numpy as np
+    i = np.arange(block * rows, (block + 1) * rows, dtype=np.uint64)
+    return {
+        "attribute_id": (sm_np(0x5EED0005, i) % np.uint64(200)).astype(np.int64),
+        "entity_id": (np.uint64(1000) + (i // np.uint64(64)) % np.uint64(50000)).astype(np.int64),
+        "time": 1_700_000_000_000 + i.astype(np.int64) * 1000,
+        "value": (sm_np(0x5EED1005, i) % np.uint64(4000)).astype(np.int64),
+    }
+
+
+def file_blocks(first_block: int, n_blocks: int, rows: int):
+    """Blocks [first_block, first_block + n_blocks) of that table as binary.Block objects:
+    array<struct{attribute_id:int, entity_id:int, time:time_milliseconds, value:int}>, the schema
+    of the reference CLI's time-series example (zbra-cli/src/main.rs:581-594)."""
+    from . import binary as zb
+    out = []
+    for b in range(first_block, first_block + n_blocks):
+        c = file_block_columns(b, rows)
+        out.append(zb.Block(rows, zb.ArrayTable(zb.Struct([
+            ("attribute_id", zb.Int(c["attribute_id"])), ("entity_id", zb.Int(c["entity_id"])),
+            ("time", zb.Int(c["time"], "TimeMilliseconds")), ("value", zb.Int(c["value"]))]))))
+    return out
