@@ -98,6 +98,16 @@ typedef struct zbra_encode_desc {
     uint32_t reserved;
 } zbra_encode_desc;
 
+/* The tag array of one Enum column of a batch (zbra_hip_enum_rows_batch_dev): all pointers are
+ * DEVICE pointers. */
+typedef struct zbra_enum_desc {
+    const uint32_t *tags; /* n tags: Column::Enum.tags            striped.rs:47-52 */
+    uint64_t n;
+    uint32_t *variant;    /* receives n variant indices */
+    uint64_t *rank;       /* receives n positions in the variants' columns */
+    uint64_t *counts;     /* receives n_variants row counts */
+} zbra_enum_desc;
+
 /* Which striped vector an int array of a .zbra image carries (the six call sites of
  * binary.rs:366-434). */
 typedef enum zbra_array_role {
@@ -208,6 +218,23 @@ int zbra_hip_decode_offsets_dev(const uint8_t *d_data, size_t len, size_t count,
  * row index itself (striped.rs:631-632). */
 int zbra_hip_enum_rows_dev(const uint32_t *d_tags, size_t n, const uint32_t *variant_tags, uint32_t n_variants,
                            uint32_t *d_variant, uint64_t *d_rank, uint64_t *d_counts, zbra_dev_result *d_result, void *stream);
+
+/* zbra_hip_decode_offsets_dev for `nd` lengths arrays in one submission: the Binary, Array and
+ * Nested lengths of one Block or of many (binary.rs:388, 399, 431 read them one after another).
+ * `descs` is a HOST array; descs[i].data / .len / .count as in zbra_hip_decode_batch_dev,
+ * descs[i].out = DEVICE pointer to count + 1 words for that array's offsets (never NULL: an empty or
+ * rejected array still gets its offsets[0] = 0), descs[i].kind = ZBRA_ELEM_I64.  d_results (may be
+ * NULL) receives nd entries.  The arrays are independent: each running sum starts at 0. */
+int zbra_hip_decode_offsets_batch_dev(const zbra_array_desc *descs, size_t nd, zbra_dev_result *d_results, void *stream);
+
+/* zbra_hip_enum_rows_dev for the tag arrays of `nd` Enum columns that share one variant list (the
+ * same column in many Blocks: Column::from_values runs once per Block, striped.rs:340-387), in one
+ * submission.  `descs` is a HOST array of DEVICE pointers; array i's variant / rank / counts are as
+ * in zbra_hip_enum_rows_dev, each array ranked on its own.  d_results (may be NULL) receives nd
+ * entries: an array with a tag that no variant carries gets ZBRA_ERR_UNKNOWN_TAG (out_count = its
+ * first such row, midpoint = the tag) and undefined outputs, the other arrays are unaffected. */
+int zbra_hip_enum_rows_batch_dev(const zbra_enum_desc *descs, size_t nd, const uint32_t *variant_tags, uint32_t n_variants,
+                                 zbra_dev_result *d_results, void *stream);
 
 /* The same for `nd` independent arrays in one submission (all arrays of a Block, or of many
  * Blocks: binary.rs:359-441 decodes them one after another).  `descs` is a HOST array whose

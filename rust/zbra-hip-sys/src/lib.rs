@@ -79,6 +79,16 @@ pub mod ffi {
     }
 
     #[repr(C)]
+    #[derive(Debug, Clone, Copy)]
+    pub struct zbra_enum_desc {
+        pub tags: *const u32,
+        pub n: u64,
+        pub variant: *mut u32,
+        pub rank: *mut u64,
+        pub counts: *mut u64,
+    }
+
+    #[repr(C)]
     #[derive(Debug, Clone, Copy, Default)]
     pub struct zbra_file_array {
         pub offset: u64,
@@ -129,6 +139,10 @@ pub mod ffi {
                                            d_result: *mut zbra_dev_result, stream: *mut c_void) -> c_int;
         pub fn zbra_hip_enum_rows_dev(d_tags: *const u32, n: usize, variant_tags: *const u32, n_variants: u32, d_variant: *mut u32,
                                       d_rank: *mut u64, d_counts: *mut u64, d_result: *mut zbra_dev_result, stream: *mut c_void) -> c_int;
+        pub fn zbra_hip_decode_offsets_batch_dev(descs: *const zbra_array_desc, nd: usize, d_results: *mut zbra_dev_result,
+                                                 stream: *mut c_void) -> c_int;
+        pub fn zbra_hip_enum_rows_batch_dev(descs: *const zbra_enum_desc, nd: usize, variant_tags: *const u32, n_variants: u32,
+                                            d_results: *mut zbra_dev_result, stream: *mut c_void) -> c_int;
         pub fn zbra_hip_decode_batch_dev(descs: *const zbra_array_desc, nd: usize, d_results: *mut zbra_dev_result,
                                          stream: *mut c_void) -> c_int;
         pub fn zbra_hip_decode_batch_dev_noalloc(descs: *const zbra_array_desc, nd: usize, d_results: *mut zbra_dev_result,

@@ -101,3 +101,61 @@ def test_invalid_arguments(env):
     counts = torch.zeros(40, dtype=torch.int64, device="cuda")
     with pytest.raises(ValueError):                                   # more variants than the kernels take
         device.enum_rows_dev(tags, list(range(33)), variant, rank, counts)
+
+
+def _run_batch(torch, device, arrays, vt):
+    """One batched submission over `arrays` (numpy uint32 tag arrays, one variant list): per array
+    (result, variant, rank, counts), guard words checked."""
+    bufs = []
+    for k, tags in enumerate(arrays):
+        n, pad = tags.size, k % 4
+        d_tags = torch.from_numpy(np.concatenate([np.zeros(pad, np.uint32), tags.astype(np.uint32)]).view(np.int32)).cuda()[pad:]
+        bufs.append((d_tags, torch.full((n + 2,), -5, dtype=torch.int32, device="cuda"), torch.full((n + 2,), -5, dtype=torch.int64, device="cuda"),
+                     torch.full((len(vt) + 2,), -5, dtype=torch.int64, device="cuda")))
+    res = device.new_results(len(arrays), "cuda")
+    device.enum_rows_batch_dev([(t, v[1:t.numel() + 1], r[1:t.numel() + 1], c[1:len(vt) + 1]) for t, v, r, c in bufs], vt, res)
+    rs = device.read_results(res)
+    out = []
+    for (t, v, r, c), res_k in zip(bufs, rs):
+        n = t.numel()
+        v, r, c = v.cpu().numpy(), r.cpu().numpy(), c.cpu().numpy()
+        assert v[0] == -5 and v[n + 1] == -5 and r[0] == -5 and r[n + 1] == -5 and c[0] == -5 and c[len(vt) + 1] == -5, "wrote outside the outputs"
+        out.append((res_k, v[1:n + 1].view(np.uint32), r[1:n + 1].view(np.uint64), c[1:len(vt) + 1].view(np.uint64)))
+    return out
+
+
+@pytest.mark.parametrize("vt", [[0, 1, 2, 7], list(range(20)), [3, 900, 70000, 3]])
+def test_batch_of_tag_arrays_each_ranked_on_its_own(env, vt):
+    """Ragged tag arrays of one Enum column in many Blocks, incl. empty ones, one that ends on a tile
+    boundary and one with a tag no variant carries: every array's variants, ranks and counts equal the
+    restated row loop run on that array alone; the bad array is reported and the others unaffected."""
+    torch, device, onp, L = env
+    rng = np.random.default_rng(len(vt))
+    pool = sorted(set(vt))
+    sizes = [0, 1, 2048, 4096 + 1, 70001, 0, 333, 2047, 1 << 17, 5, 12288, 100003, 0]
+    arrays = [rng.choice(pool, n).astype(np.uint64).astype(np.uint32) for n in sizes]
+    bad_at, bad_row = 6, 200
+    arrays[bad_at][bad_row] = 123456
+    got = _run_batch(torch, device, arrays, vt)
+    for k, (tags, (r, gv, gr, gc)) in enumerate(zip(arrays, got)):
+        st, variant, rank, counts, first = onp.enum_rows(tags, vt)
+        if k == bad_at:
+            assert st == 8 and r.status == L.ERR_UNKNOWN_TAG and r.out_count == first == bad_row and r.midpoint == 123456
+            continue
+        assert st == 0 and r.status == 0 and r.out_count == tags.size, k
+        assert np.array_equal(gv, variant) and np.array_equal(gr, rank) and np.array_equal(gc, counts), (k, tags.size)
+
+
+def test_batch_equals_single_calls_and_empty_batch(env):
+    torch, device, onp, L = env
+    rng = np.random.default_rng(31)
+    vt = [0, 1, 2, 7]
+    arrays = [rng.choice(vt, n, p=[.5, .25, .15, .1]).astype(np.uint32) for n in (1 << 15, (1 << 15) + 77, 9, 1 << 16)]
+    got = _run_batch(torch, device, arrays, vt)
+    for tags, (r, gv, gr, gc) in zip(arrays, got):
+        r1, v1, k1, c1 = _run(torch, device, tags, vt)
+        assert r.status == r1.status == 0 and np.array_equal(gv, v1) and np.array_equal(gr, k1) and np.array_equal(gc, c1)
+    assert L.lib.zbra_hip_enum_rows_batch_dev(None, 0, None, 0, None, None) == 0
+    # only empty arrays: counts are written (zeros), nothing else
+    got = _run_batch(torch, device, [np.zeros(0, np.uint32)] * 3, vt)
+    assert all(r.status == 0 and r.out_count == 0 and gc.tolist() == [0, 0, 0, 0] for r, _, _, gc in got)

@@ -28,6 +28,11 @@ class EncodeDesc(C.Structure):
                 ("kind", C.c_uint32), ("reserved", C.c_uint32)]
 
 
+class EnumDesc(C.Structure):
+    """zbra_enum_desc of include/zbra_hip.h."""
+    _fields_ = [("tags", C.c_void_p), ("n", C.c_uint64), ("variant", C.c_void_p), ("rank", C.c_void_p), ("counts", C.c_void_p)]
+
+
 class FileArray(C.Structure):
     """zbra_file_array of include/zbra_hip.h."""
     _fields_ = [("offset", C.c_uint64), ("len", C.c_uint64), ("count", C.c_uint64), ("kind", C.c_uint32),
@@ -67,6 +72,8 @@ SIGNATURES = {
     "zbra_hip_decode_dev": (C.c_int, [_p, _sz, _sz, _p, C.c_uint32, _p, _p]),
     "zbra_hip_decode_offsets_dev": (C.c_int, [_p, _sz, _sz, _p, _p, _p]),
     "zbra_hip_enum_rows_dev": (C.c_int, [_p, _sz, _p, C.c_uint32, _p, _p, _p, _p, _p]),
+    "zbra_hip_decode_offsets_batch_dev": (C.c_int, [C.POINTER(ArrayDesc), _sz, _p, _p]),
+    "zbra_hip_enum_rows_batch_dev": (C.c_int, [C.POINTER(EnumDesc), _sz, _p, C.c_uint32, _p, _p]),
     "zbra_hip_decode_batch_dev": (C.c_int, [C.POINTER(ArrayDesc), _sz, _p, _p]),
     "zbra_hip_decode_batch_dev_noalloc": (C.c_int, [C.POINTER(ArrayDesc), _sz, _p, _p]),
     "zbra_hip_encode_dev": (C.c_int, [_p, _sz, C.c_uint32, _p, _sz, _p, _p]),

@@ -425,6 +425,176 @@ static int decode_batch_dev(DeviceCtx *ctx, const zbra_array_desc *descs, size_t
     return st != ZBRA_OK ? st : st2;
 }
 
+// ---- lengths -> offsets, device-resident ------------------------------------------------------
+
+// descs[i].out: count + 1 offsets of array i.  One submission: plan, per-tile sums, a two-level scan
+// of the tile sums of all arrays as one sequence, the write pass.
+static int decode_offsets_batch_dev(DeviceCtx *ctx, const zbra_array_desc *descs, size_t nd, zbra_dev_result *d_results, hipStream_t stream) {
+    if (nd == 0) return ZBRA_OK;
+    if (!descs) return ZBRA_ERR_INVALID_ARG;
+    uint64_t ntiles = 0, all_bytes = 0;
+    bool any_empty = false;
+    for (size_t i = 0; i < nd; i++) {
+        const zbra_array_desc &d = descs[i];
+        if (d.count > MAX_COUNT || d.kind != ZBRA_ELEM_I64 || !d.out || (d.len && !d.data)) return ZBRA_ERR_INVALID_ARG;
+        ntiles += (d.count + OFF_TILE - 1) / OFF_TILE;
+        all_bytes += d.len;
+        any_empty = any_empty || d.count == 0;
+    }
+    // one workgroup per tile in the write pass: a longer table goes down in pieces (arrays are independent)
+    const uint64_t most_tiles = launch_limit() / OFF_THREADS;
+    if (nd > 1 && (ntiles > most_tiles || nd > MAX_BATCH_ARRAYS)) {
+        size_t first = 0;
+        while (first < nd) {
+            size_t end = first;
+            uint64_t t = 0;
+            while (end < nd && end - first < MAX_BATCH_ARRAYS) {
+                const uint64_t ti = (descs[end].count + OFF_TILE - 1) / OFF_TILE;
+                if (end > first && t + ti > most_tiles) break;
+                t += ti;
+                end++;
+            }
+            ZBRA_TRY(decode_offsets_batch_dev(ctx, descs + first, end - first, d_results ? d_results + first : nullptr, stream));
+            first = end;
+        }
+        return ZBRA_OK;
+    }
+    const uint64_t nchunks = (ntiles + SCAN_CHUNK - 1) / SCAN_CHUNK;
+    const size_t off_ts = align_up(nd * sizeof(zbra_array_desc), 64);
+    const size_t host_bytes = off_ts + (nd + 1) * sizeof(uint64_t);
+    const size_t off_plan = align_up(host_bytes, 64);
+    const size_t off_map = align_up(off_plan + nd * sizeof(DecodePlan), 64);
+    const size_t off_sums = align_up(off_map + (nd > 1 ? (size_t)ntiles * sizeof(uint32_t) : 0), 64);
+    const size_t total = off_sums + (size_t)(ntiles + nchunks + 1) * sizeof(uint64_t);
+    Slot *s;
+    ZBRA_TRY(ctx->acquire(total, &s, host_bytes));
+    std::memcpy(s->host, descs, nd * sizeof(zbra_array_desc));
+    uint64_t *h_ts = (uint64_t *)((char *)s->host + off_ts);
+    uint64_t run = 0;
+    for (size_t i = 0; i < nd; i++) { h_ts[i] = run; run += (descs[i].count + OFF_TILE - 1) / OFF_TILE; }
+    h_ts[nd] = run;
+    int st = hip_status(hipMemcpyAsync(s->dev, s->host, host_bytes, hipMemcpyHostToDevice, stream));
+    if (st == ZBRA_OK) {
+        const zbra_array_desc *d_descs = (const zbra_array_desc *)s->dev;
+        const uint64_t *d_ts = (const uint64_t *)((char *)s->dev + off_ts);
+        DecodePlan *d_plans = (DecodePlan *)((char *)s->dev + off_plan);
+        uint32_t *d_map = nd > 1 ? (uint32_t *)((char *)s->dev + off_map) : nullptr;
+        uint64_t *tile_sums = (uint64_t *)((char *)s->dev + off_sums);
+        uint64_t *chunk_base = tile_sums + ntiles;
+        if (nd == 1)
+            hipLaunchKernelGGL(plan_decode_one_kernel, dim3(1), dim3(64), 0, stream, descs[0], ntiles, d_plans, (uint64_t *)d_ts, d_results);
+        else
+            hipLaunchKernelGGL(plan_decode_batch_kernel, dim3((unsigned)nd), dim3(256), 0, stream, d_descs, (uint32_t)nd, d_ts, d_plans, d_map,
+                               d_results, (const uint32_t *)nullptr);
+        if (any_empty) hipLaunchKernelGGL(offsets_empty_kernel, dim3((unsigned)((nd + 255) / 256)), dim3(256), 0, stream, d_descs, (uint32_t)nd);
+        if (ntiles) {
+            hipLaunchKernelGGL(offsets_sums_kernel, dim3((unsigned)((ntiles + OFF_SUM_WAVES - 1) / OFF_SUM_WAVES)), dim3(64 * OFF_SUM_WAVES), 0, stream,
+                               d_plans, d_ts, d_map, (uint32_t)nd, ntiles, tile_sums);
+            hipLaunchKernelGGL(offsets_scan_chunks_kernel, dim3((unsigned)nchunks), dim3(SCAN_CHUNK), 0, stream, ntiles, tile_sums, chunk_base);
+            hipLaunchKernelGGL(offsets_scan_totals_kernel, dim3(1), dim3(SCAN_CHUNK), 0, stream, nchunks, chunk_base);
+            // the write pass finds the packed bytes in the memory-side cache (256 MB) if the sums pass left them there:
+            // all of them when they are few enough, else the ones it read last, which a back-to-front pass meets first
+            hipLaunchKernelGGL(offsets_write_kernel, dim3((unsigned)ntiles), dim3(OFF_THREADS), 0, stream, d_plans, d_ts, d_map, (uint32_t)nd, tile_sums,
+                               chunk_base, all_bytes > ((uint64_t)208 << 20) ? 1u : 0u);
+        }
+        st = hip_status(hipGetLastError());
+    }
+    int st2 = ctx->release(s, stream);
+    return st != ZBRA_OK ? st : st2;
+}
+
+// ---- Enum rows -> (variant, rank), device-resident ---------------------------------------------
+
+static int enum_rows_batch_dev(DeviceCtx *ctx, const zbra_enum_desc *descs, size_t nd, const uint32_t *variant_tags, uint32_t n_variants,
+                               zbra_dev_result *d_results, hipStream_t stream) {
+    if (nd == 0) return ZBRA_OK;
+    if (!descs || n_variants > (uint32_t)ENUM_MAX_VARIANTS || (n_variants && !variant_tags)) return ZBRA_ERR_INVALID_ARG;
+    uint64_t ntiles = 0, all_rows = 0;
+    for (size_t i = 0; i < nd; i++) {
+        const zbra_enum_desc &d = descs[i];
+        if (d.n > MAX_COUNT || (n_variants && !d.counts) || (d.n && (!d.tags || !d.variant || !d.rank))) return ZBRA_ERR_INVALID_ARG;
+        ntiles += (d.n + ENUM_TILE - 1) / ENUM_TILE;
+        all_rows += d.n;
+    }
+    // one workgroup per tile in the write pass: a longer table goes down in pieces (arrays are independent)
+    const uint64_t most_tiles = launch_limit() / ENUM_THREADS;
+    if (nd > 1 && (ntiles > most_tiles || nd > MAX_BATCH_ARRAYS)) {
+        size_t first = 0;
+        while (first < nd) {
+            size_t end = first;
+            uint64_t t = 0;
+            while (end < nd && end - first < MAX_BATCH_ARRAYS) {
+                const uint64_t ti = (descs[end].n + ENUM_TILE - 1) / ENUM_TILE;
+                if (end > first && t + ti > most_tiles) break;
+                t += ti;
+                end++;
+            }
+            ZBRA_TRY(enum_rows_batch_dev(ctx, descs + first, end - first, variant_tags, n_variants, d_results ? d_results + first : nullptr, stream));
+            first = end;
+        }
+        return ZBRA_OK;
+    }
+    const uint64_t nchunks = (ntiles + SCAN_CHUNK - 1) / SCAN_CHUNK;
+    // host-filled: variant tags, descriptors, first tile of each array
+    const size_t off_desc = align_up(ENUM_MAX_VARIANTS * sizeof(uint32_t), 64);
+    const size_t off_ts = align_up(off_desc + nd * sizeof(zbra_enum_desc), 64);
+    const size_t host_bytes = off_ts + (nd + 1) * sizeof(uint64_t);
+    // device only: first unknown-tag row of each array, tile -> array, per-variant tile counts and chunk prefixes
+    const size_t off_bad = align_up(host_bytes, 64);
+    const size_t off_map = align_up(off_bad + nd * sizeof(unsigned long long), 64);
+    const size_t off_counts = align_up(off_map + (nd > 1 ? (size_t)ntiles * sizeof(uint32_t) : 0), 64);
+    const size_t total = off_counts + (size_t)n_variants * (ntiles + nchunks + 1) * sizeof(uint64_t);
+    Slot *s;
+    ZBRA_TRY(ctx->acquire(total, &s, host_bytes));
+    uint32_t *h_vt = (uint32_t *)s->host;
+    for (uint32_t v = 0; v < (uint32_t)ENUM_MAX_VARIANTS; v++) h_vt[v] = v < n_variants ? variant_tags[v] : 0;
+    std::memcpy((char *)s->host + off_desc, descs, nd * sizeof(zbra_enum_desc));
+    uint64_t *h_ts = (uint64_t *)((char *)s->host + off_ts);
+    uint64_t run = 0;
+    for (size_t i = 0; i < nd; i++) { h_ts[i] = run; run += (descs[i].n + ENUM_TILE - 1) / ENUM_TILE; }
+    h_ts[nd] = run;
+    const uint32_t *d_vt = (const uint32_t *)s->dev;
+    unsigned long long *d_bad = (unsigned long long *)((char *)s->dev + off_bad);
+    uint64_t *tile_counts = (uint64_t *)((char *)s->dev + off_counts);
+    uint64_t *chunk_base = tile_counts + (size_t)n_variants * ntiles;
+    EnumBatch batch;
+    batch.arrays = (const zbra_enum_desc *)((char *)s->dev + off_desc);
+    batch.tile_start = (const uint64_t *)((char *)s->dev + off_ts);
+    batch.tile_map = nd > 1 ? (const uint32_t *)((char *)s->dev + off_map) : nullptr;
+    batch.nd = (uint32_t)nd;
+    batch.ntiles = ntiles;
+    int st = hip_status(hipMemcpyAsync(s->dev, s->host, host_bytes, hipMemcpyHostToDevice, stream));
+    if (st == ZBRA_OK) {
+        hipLaunchKernelGGL(enum_map_kernel, dim3((unsigned)nd), dim3(256), 0, stream, batch, (uint32_t *)((char *)s->dev + off_map), d_bad);
+        if (ntiles) {
+            if (n_variants <= (uint32_t)ENUM_FEW) {
+                const uint64_t per_wg = (uint64_t)ENUM_WAVES * ENUM_COUNT_TILES;
+                hipLaunchKernelGGL(enum_counts_few_kernel, dim3((unsigned)((ntiles + per_wg - 1) / per_wg)), dim3(ENUM_THREADS), 0, stream, batch, d_vt,
+                                   n_variants, tile_counts, d_bad);
+            } else {
+                hipLaunchKernelGGL(enum_counts_kernel, dim3((unsigned)ntiles), dim3(ENUM_THREADS), 0, stream, batch, d_vt, n_variants, tile_counts, d_bad);
+            }
+            if (n_variants) {
+                hipLaunchKernelGGL(enum_scan_chunks_kernel, dim3((unsigned)nchunks, n_variants), dim3(SCAN_CHUNK), 0, stream, ntiles, nchunks,
+                                   tile_counts, chunk_base);
+                hipLaunchKernelGGL(enum_scan_totals_kernel, dim3(n_variants), dim3(SCAN_CHUNK), 0, stream, nchunks, chunk_base);
+            }
+        }
+        if (n_variants)  // with no tile at all every count is zero, and the kernel reads nothing of the scans
+            hipLaunchKernelGGL(enum_array_counts_kernel, dim3((unsigned)((nd * n_variants + 255) / 256)), dim3(256), 0, stream, batch, n_variants, nchunks,
+                               tile_counts, chunk_base);
+        if (ntiles) {
+            const int rev = tuning().enum_reverse;
+            hipLaunchKernelGGL(enum_write_kernel, dim3((unsigned)ntiles), dim3(ENUM_THREADS), 0, stream, batch, d_vt, n_variants, nchunks, tile_counts,
+                               chunk_base, rev < 0 ? (all_rows * 4 > ((uint64_t)208 << 20) ? 1u : 0u) : (uint32_t)rev);
+        }
+        hipLaunchKernelGGL(enum_report_kernel, dim3((unsigned)((nd + 255) / 256)), dim3(256), 0, stream, batch, d_bad, d_results);
+        st = hip_status(hipGetLastError());
+    }
+    int st2 = ctx->release(s, stream);
+    return st != ZBRA_OK ? st : st2;
+}
+
 // ---- decode, device-resident, no allocation --------------------------------------------------
 
 // Up to NOALLOC_CHUNK descriptors and their tile scan travel in the kernel arguments (about 3 KB),
@@ -1170,80 +1340,33 @@ int zbra_hip_decode_dev(const uint8_t *d_data, size_t len, size_t count, void *d
 int zbra_hip_decode_offsets_dev(const uint8_t *d_data, size_t len, size_t count, uint64_t *d_offsets, zbra_dev_result *d_result,
                                 void *stream_) {
     if (!d_offsets || (len && !d_data) || count > MAX_COUNT) return ZBRA_ERR_INVALID_ARG;
+    zbra_array_desc d;
+    d.data = d_data; d.len = len; d.count = count; d.out = d_offsets; d.kind = ZBRA_ELEM_I64; d.reserved = 0;
     DeviceCtx *ctx;
     ZBRA_TRY(current_ctx(&ctx));
-    hipStream_t stream = (hipStream_t)stream_;
-    const uint64_t ntiles = ((uint64_t)count + OFF_TILE - 1) / OFF_TILE;
-    const uint64_t nchunks = (ntiles + SCAN_CHUNK - 1) / SCAN_CHUNK;
-    Slot *s;
-    ZBRA_TRY(ctx->acquire(128 + (size_t)(ntiles + nchunks + 1) * sizeof(uint64_t), &s, 64));  // nothing comes from the host
-    DecodePlan *plan = (DecodePlan *)s->dev;
-    uint64_t *tile_start = (uint64_t *)((char *)s->dev + 64);  // written by the plan kernel, not used here
-    uint64_t *tile_sums = (uint64_t *)((char *)s->dev + 128);
-    uint64_t *chunk_base = tile_sums + ntiles;
-    zbra_array_desc d;
-    d.data = d_data; d.len = len; d.count = count; d.out = d_offsets + 1; d.kind = ZBRA_ELEM_I64; d.reserved = 0;
-    hipLaunchKernelGGL(plan_decode_one_kernel, dim3(1), dim3(64), 0, stream, d, ntiles, plan, tile_start, d_result);
-    if (ntiles) {
-        hipLaunchKernelGGL(offsets_sums_kernel, dim3((unsigned)((ntiles + OFF_SUM_WAVES - 1) / OFF_SUM_WAVES)), dim3(64 * OFF_SUM_WAVES), 0, stream, plan,
-                           tile_sums);
-        hipLaunchKernelGGL(offsets_scan_chunks_kernel, dim3((unsigned)nchunks), dim3(SCAN_CHUNK), 0, stream, plan, tile_sums, chunk_base);
-        hipLaunchKernelGGL(offsets_scan_totals_kernel, dim3(1), dim3(SCAN_CHUNK), 0, stream, plan, chunk_base);
-    }
-    // the write pass finds the packed bytes in the memory-side cache (256 MB) if the sums pass left them there:
-    // all of them when they are few enough, else the ones it read last, which a back-to-front pass meets first
-    hipLaunchKernelGGL(offsets_write_kernel, dim3((unsigned)(ntiles ? ntiles : 1)), dim3(OFF_THREADS), 0, stream, plan, tile_sums, chunk_base,
-                       d_offsets, len > ((size_t)208 << 20) ? 1u : 0u);
-    int st = hip_status(hipGetLastError());
-    int st2 = ctx->release(s, stream);
-    return st != ZBRA_OK ? st : st2;
+    return decode_offsets_batch_dev(ctx, &d, 1, d_result, (hipStream_t)stream_);
+}
+
+int zbra_hip_decode_offsets_batch_dev(const zbra_array_desc *descs, size_t nd, zbra_dev_result *d_results, void *stream) {
+    DeviceCtx *ctx;
+    ZBRA_TRY(current_ctx(&ctx));
+    return decode_offsets_batch_dev(ctx, descs, nd, d_results, (hipStream_t)stream);
 }
 
 int zbra_hip_enum_rows_dev(const uint32_t *d_tags, size_t n, const uint32_t *variant_tags, uint32_t n_variants,
                            uint32_t *d_variant, uint64_t *d_rank, uint64_t *d_counts, zbra_dev_result *d_result, void *stream_) {
-    if (n_variants > (uint32_t)ENUM_MAX_VARIANTS || (n_variants && (!variant_tags || !d_counts)) || n > MAX_COUNT ||
-        (n && (!d_tags || !d_variant || !d_rank)))
-        return ZBRA_ERR_INVALID_ARG;
+    zbra_enum_desc d;
+    d.tags = d_tags; d.n = n; d.variant = d_variant; d.rank = d_rank; d.counts = d_counts;
     DeviceCtx *ctx;
     ZBRA_TRY(current_ctx(&ctx));
-    hipStream_t stream = (hipStream_t)stream_;
-    const uint64_t ntiles = ((uint64_t)n + ENUM_TILE - 1) / ENUM_TILE;
-    const uint64_t nchunks = (ntiles + SCAN_CHUNK - 1) / SCAN_CHUNK;
-    const size_t off_bad = ENUM_MAX_VARIANTS * sizeof(uint32_t), off_counts = 256;
-    Slot *s;
-    ZBRA_TRY(ctx->acquire(off_counts + (size_t)n_variants * (ntiles + nchunks) * sizeof(uint64_t), &s, off_bad));
-    uint32_t *h_vt = (uint32_t *)s->host;
-    for (uint32_t v = 0; v < (uint32_t)ENUM_MAX_VARIANTS; v++) h_vt[v] = v < n_variants ? variant_tags[v] : 0;
-    const uint32_t *d_vt = (const uint32_t *)s->dev;
-    unsigned long long *d_bad = (unsigned long long *)((char *)s->dev + off_bad);
-    uint64_t *tile_counts = (uint64_t *)((char *)s->dev + off_counts);
-    uint64_t *chunk_base = tile_counts + (size_t)n_variants * ntiles;
-    int st = hip_status(hipMemcpyAsync(s->dev, s->host, off_bad, hipMemcpyHostToDevice, stream));
-    if (st == ZBRA_OK) st = hip_status(hipMemsetAsync(d_bad, 0xFF, sizeof(unsigned long long), stream));
-    if (st == ZBRA_OK && n_variants && ntiles == 0) st = hip_status(hipMemsetAsync(d_counts, 0, n_variants * sizeof(uint64_t), stream));
-    if (st == ZBRA_OK) {
-        if (ntiles) {
-            if (n_variants <= (uint32_t)ENUM_FEW) {
-                const uint64_t per_wg = (uint64_t)ENUM_WAVES * ENUM_COUNT_TILES;
-                hipLaunchKernelGGL(enum_counts_few_kernel, dim3((unsigned)((ntiles + per_wg - 1) / per_wg)), dim3(ENUM_THREADS), 0, stream, d_tags,
-                                   (uint64_t)n, d_vt, n_variants, ntiles, tile_counts, d_bad);
-            } else {
-                hipLaunchKernelGGL(enum_counts_kernel, dim3((unsigned)ntiles), dim3(ENUM_THREADS), 0, stream, d_tags, (uint64_t)n, d_vt, n_variants,
-                                   ntiles, tile_counts, d_bad);
-            }
-            if (n_variants) {
-                hipLaunchKernelGGL(enum_scan_chunks_kernel, dim3((unsigned)nchunks, n_variants), dim3(SCAN_CHUNK), 0, stream, ntiles, nchunks,
-                                   tile_counts, chunk_base);
-                hipLaunchKernelGGL(enum_scan_totals_kernel, dim3(n_variants), dim3(SCAN_CHUNK), 0, stream, nchunks, chunk_base, d_counts);
-            }
-            hipLaunchKernelGGL(enum_write_kernel, dim3((unsigned)ntiles), dim3(ENUM_THREADS), 0, stream, d_tags, (uint64_t)n, d_vt, n_variants,
-                               ntiles, nchunks, tile_counts, chunk_base, d_variant, d_rank, tuning().enum_reverse < 0 ? ((uint64_t)n * 4 > ((uint64_t)208 << 20) ? 1u : 0u) : (uint32_t)tuning().enum_reverse);
-        }
-        hipLaunchKernelGGL(enum_report_kernel, dim3(1), dim3(64), 0, stream, d_tags, (uint64_t)n, d_bad, d_result);
-        st = hip_status(hipGetLastError());
-    }
-    int st2 = ctx->release(s, stream);
-    return st != ZBRA_OK ? st : st2;
+    return enum_rows_batch_dev(ctx, &d, 1, variant_tags, n_variants, d_result, (hipStream_t)stream_);
+}
+
+int zbra_hip_enum_rows_batch_dev(const zbra_enum_desc *descs, size_t nd, const uint32_t *variant_tags, uint32_t n_variants,
+                                 zbra_dev_result *d_results, void *stream) {
+    DeviceCtx *ctx;
+    ZBRA_TRY(current_ctx(&ctx));
+    return enum_rows_batch_dev(ctx, descs, nd, variant_tags, n_variants, d_results, (hipStream_t)stream);
 }
 
 int zbra_hip_decode_batch_dev(const zbra_array_desc *descs, size_t nd, zbra_dev_result *d_results, void *stream) {

@@ -13,6 +13,12 @@
 // (per variant), and a second read of the tags that adds the pieces up.  HBM traffic: the tags
 // twice (4 B each), 4 + 8 B written per row.
 //
+// A submission holds the tag arrays of any number of independent Enum columns with the same variant
+// list (the same column in many Blocks): tile T of the submission belongs to array a = tile_map[T]
+// and is that array's tile T - tile_start[a].  The per-variant tile counts of ALL arrays are scanned
+// as one sequence, and an array's ranks start at zero because its tiles subtract the scanned value
+// of the array's first tile.
+//
 // The other direction (Column::to_values, striped.rs:617-657) needs no kernel: the reference reads
 // variant column v at the ROW index (`values[row_idx]`, :631-632), not at the rank.
 #pragma once
@@ -29,6 +35,20 @@ constexpr int ENUM_PER = ENUM_TILE / ENUM_THREADS;  // rows per lane: a wave own
 constexpr uint32_t ENUM_LUT = 256;     // variant tags below this are looked up, not searched
 constexpr uint32_t ENUM_NONE = 0xFFFFFFFFu;
 constexpr int ENUM_FEW = 8;            // up to this many variants the counting pass keeps byte counters in two registers
+
+// The arrays of one submission (device memory, except nd / ntiles).
+struct EnumBatch {
+    const zbra_enum_desc *arrays;  // tags, n, variant, rank, counts of each array
+    const uint64_t *tile_start;    // nd + 1: first tile of each array
+    const uint32_t *tile_map;      // tile -> array (not read when nd == 1)
+    uint32_t nd;
+    uint64_t ntiles;
+};
+// Array and first tile of that array for tile T of the submission.
+__device__ __forceinline__ void enum_locate(const EnumBatch &b, uint64_t T, uint32_t &a, uint64_t &S) {
+    a = b.nd > 1 ? b.tile_map[T] : 0u;
+    S = b.tile_start[a];
+}
 
 struct EnumShared {
     uint32_t vtag[ENUM_MAX_VARIANTS];
@@ -99,23 +119,26 @@ __device__ __forceinline__ void enum_wave_rows(EnumShared &sh, const uint32_t *_
 }
 
 // 1. tile_counts[v * ntiles + t] = rows of variant v in tile t.
-__global__ __launch_bounds__(ENUM_THREADS) void enum_counts_kernel(const uint32_t *__restrict__ tags, uint64_t n,
-                                                                    const uint32_t *__restrict__ variant_tags, uint32_t nv, uint64_t ntiles,
+__global__ __launch_bounds__(ENUM_THREADS) void enum_counts_kernel(EnumBatch batch, const uint32_t *__restrict__ variant_tags, uint32_t nv,
                                                                     uint64_t *__restrict__ tile_counts, unsigned long long *first_bad_row) {
     __shared__ EnumShared sh;
     enum_setup(sh, variant_tags, nv);
-    const uint64_t tile = blockIdx.x;
+    const uint64_t T = blockIdx.x;
+    uint32_t a;
+    uint64_t S;
+    enum_locate(batch, T, a, S);
+    const zbra_enum_desc d = batch.arrays[a];
     uint64_t bad = ~0ull;
     uint32_t v[ENUM_PER], r[ENUM_PER];
-    enum_wave_rows(sh, tags, tile * ENUM_TILE, n, nv, v, r, bad);
+    enum_wave_rows(sh, d.tags, (T - S) * ENUM_TILE, d.n, nv, v, r, bad);
     bad = wave_min_u64(bad);
-    if ((threadIdx.x & 63u) == 0 && bad != ~0ull) atomicMin(first_bad_row, (unsigned long long)bad);
+    if ((threadIdx.x & 63u) == 0 && bad != ~0ull) atomicMin(first_bad_row + a, (unsigned long long)bad);
     __syncthreads();
     if (threadIdx.x < nv) {
         uint32_t c = 0;
 #pragma unroll
         for (int w = 0; w < ENUM_WAVES; w++) c += sh.wcnt[w][threadIdx.x];
-        tile_counts[(uint64_t)threadIdx.x * ntiles + tile] = c;
+        tile_counts[(uint64_t)threadIdx.x * batch.ntiles + T] = c;
     }
 }
 
@@ -148,9 +171,9 @@ __device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v) {
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
     return v;
 }
-__global__ __launch_bounds__(ENUM_THREADS) void enum_counts_few_kernel(const uint32_t *__restrict__ tags, uint64_t n,
-                                                                        const uint32_t *__restrict__ variant_tags, uint32_t nv, uint64_t ntiles,
+__global__ __launch_bounds__(ENUM_THREADS) void enum_counts_few_kernel(EnumBatch batch, const uint32_t *__restrict__ variant_tags, uint32_t nv,
                                                                         uint64_t *__restrict__ tile_counts, unsigned long long *first_bad_row) {
+    const uint64_t ntiles = batch.ntiles;
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
     uint32_t vt[ENUM_FEW], live = 0;  // uniform; a variant whose tag an earlier one carries never gets a row (striped.rs:349)
 #pragma unroll
@@ -160,12 +183,18 @@ __global__ __launch_bounds__(ENUM_THREADS) void enum_counts_few_kernel(const uin
         for (int a = 0; a < b; a++) first = first && vt[a] != vt[b];
         live |= first ? 1u << b : 0u;
     }
-    const bool aligned = ((uintptr_t)tags & 15u) == 0;  // tiles start at multiples of 8 KiB from `tags`
-    uint64_t bad = ~0ull;
     for (int q = 0; q < ENUM_COUNT_TILES; q++) {
-        const uint64_t tile = ((uint64_t)blockIdx.x * ENUM_WAVES + wave) * ENUM_COUNT_TILES + q;
+        const uint64_t tile = ((uint64_t)blockIdx.x * ENUM_WAVES + wave) * ENUM_COUNT_TILES + q;  // of the submission
         if (tile >= ntiles) break;  // uniform within the wave
-        const uint64_t r0 = tile * ENUM_TILE;
+        uint32_t a;
+        uint64_t S;
+        enum_locate(batch, tile, a, S);
+        const zbra_enum_desc d = batch.arrays[a];
+        const uint32_t *__restrict__ tags = d.tags;
+        const uint64_t n = d.n;
+        const bool aligned = ((uintptr_t)tags & 15u) == 0;  // tiles start at multiples of 8 KiB from `tags`
+        uint64_t bad = ~0ull;
+        const uint64_t r0 = (tile - S) * ENUM_TILE;
         uint32_t lo = 0, hi = 0;
         if (aligned && r0 + ENUM_TILE <= n) {
             const ZBRA_GLOBAL u32x4 *src = (const ZBRA_GLOBAL u32x4 *)(gptr<uint32_t>(tags) + r0) + lane;
@@ -218,14 +247,15 @@ __global__ __launch_bounds__(ENUM_THREADS) void enum_counts_few_kernel(const uin
                     if (!any) bad = row;
                 }
             }
+            bad = wave_min_u64(bad);
+            if (lane == 0 && bad != ~0ull) atomicMin(first_bad_row + a, (unsigned long long)bad);
         }
     }
-    bad = wave_min_u64(bad);
-    if (lane == 0 && bad != ~0ull) atomicMin(first_bad_row, (unsigned long long)bad);
 }
 
 // 2. Exclusive scan of every variant's tile counts, two levels, as for the offsets: blockIdx.y is
-// the variant.  The second level also leaves counts[v].
+// the variant.  chunk_base holds nchunks + 1 words per variant: the second level leaves the
+// variant's total over the whole submission in the last one.
 __global__ __launch_bounds__(SCAN_CHUNK) void enum_scan_chunks_kernel(uint64_t ntiles, uint64_t nchunks, uint64_t *__restrict__ tile_counts,
                                                                        uint64_t *__restrict__ chunk_base) {
     __shared__ uint64_t wtot[SCAN_CHUNK / 64];
@@ -235,12 +265,11 @@ __global__ __launch_bounds__(SCAN_CHUNK) void enum_scan_chunks_kernel(uint64_t n
     uint64_t total;
     const uint64_t ex = block_exclusive_scan_1024(x, wtot, &total);
     if (t < ntiles) col[t] = ex;
-    if (threadIdx.x == 0) chunk_base[(uint64_t)blockIdx.y * nchunks + blockIdx.x] = total;
+    if (threadIdx.x == 0) chunk_base[(uint64_t)blockIdx.y * (nchunks + 1) + blockIdx.x] = total;
 }
-__global__ __launch_bounds__(SCAN_CHUNK) void enum_scan_totals_kernel(uint64_t nchunks, uint64_t *__restrict__ chunk_base,
-                                                                       uint64_t *__restrict__ counts) {
+__global__ __launch_bounds__(SCAN_CHUNK) void enum_scan_totals_kernel(uint64_t nchunks, uint64_t *__restrict__ chunk_base) {
     __shared__ uint64_t wtot[SCAN_CHUNK / 64];
-    uint64_t *col = chunk_base + (uint64_t)blockIdx.x * nchunks;  // blockIdx.x is the variant
+    uint64_t *col = chunk_base + (uint64_t)blockIdx.x * (nchunks + 1);  // blockIdx.x is the variant
     uint64_t carry = 0;
     for (uint64_t c0 = 0; c0 < nchunks; c0 += SCAN_CHUNK) {  // uniform trip count
         const uint64_t c = c0 + threadIdx.x;
@@ -250,28 +279,52 @@ __global__ __launch_bounds__(SCAN_CHUNK) void enum_scan_totals_kernel(uint64_t n
         if (c < nchunks) col[c] = carry + ex;
         carry += total;
     }
-    if (threadIdx.x == 0) counts[blockIdx.x] = carry;
+    if (threadIdx.x == 0) col[nchunks] = carry;
+}
+
+// Rows of variant v in the submission's tiles before tile T (T == ntiles: in all of them).
+__device__ __forceinline__ uint64_t enum_prefix(const uint64_t *__restrict__ tile_counts, const uint64_t *__restrict__ chunk_base, uint64_t ntiles,
+                                                uint64_t nchunks, uint32_t v, uint64_t T) {
+    const uint64_t *col = chunk_base + (uint64_t)v * (nchunks + 1);
+    return T < ntiles ? col[T / SCAN_CHUNK] + tile_counts[(uint64_t)v * ntiles + T] : col[nchunks];
+}
+
+// 2b. counts[v] of every array: rows of variant v in its tiles.  One lane per (array, variant).
+__global__ void enum_array_counts_kernel(EnumBatch batch, uint32_t nv, uint64_t nchunks, const uint64_t *__restrict__ tile_counts,
+                                         const uint64_t *__restrict__ chunk_base) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (uint64_t)batch.nd * nv) return;
+    const uint32_t a = (uint32_t)(i / nv), v = (uint32_t)(i % nv);
+    const uint64_t S = batch.tile_start[a], E = batch.tile_start[a + 1];
+    batch.arrays[a].counts[v] = E == S ? 0 : enum_prefix(tile_counts, chunk_base, batch.ntiles, nchunks, v, E) -
+                                             enum_prefix(tile_counts, chunk_base, batch.ntiles, nchunks, v, S);
 }
 
 // 3. variant[i] and rank[i]: rows of the variant in earlier tiles + in earlier waves of the tile +
 // earlier in the wave.  A submission with an unknown tag is reported, its outputs are not defined.
-__global__ __launch_bounds__(ENUM_THREADS) void enum_write_kernel(const uint32_t *__restrict__ tags, uint64_t n,
-                                                                   const uint32_t *__restrict__ variant_tags, uint32_t nv, uint64_t ntiles,
+__global__ __launch_bounds__(ENUM_THREADS) void enum_write_kernel(EnumBatch batch, const uint32_t *__restrict__ variant_tags, uint32_t nv,
                                                                    uint64_t nchunks, const uint64_t *__restrict__ tile_counts,
-                                                                   const uint64_t *__restrict__ chunk_base, uint32_t *__restrict__ variant,
-                                                                   uint64_t *__restrict__ rank, uint32_t reverse) {
+                                                                   const uint64_t *__restrict__ chunk_base, uint32_t reverse) {
     __shared__ EnumShared sh;
     __shared__ uint64_t start[ENUM_WAVES][ENUM_MAX_VARIANTS];  // rank of the wave's first row of each variant
     enum_setup(sh, variant_tags, nv);
     // back to front when the tags are more than the memory-side cache holds: what the counting pass
     // read last is what is still there
-    const uint64_t tile = reverse ? gridDim.x - 1 - blockIdx.x : blockIdx.x;
+    const uint64_t T = reverse ? gridDim.x - 1 - blockIdx.x : blockIdx.x;
+    uint32_t a;
+    uint64_t S;
+    enum_locate(batch, T, a, S);
+    const zbra_enum_desc d = batch.arrays[a];
+    const uint64_t n = d.n, tile = T - S;
+    uint32_t *__restrict__ variant = d.variant;
+    uint64_t *__restrict__ rank = d.rank;
     uint32_t v[ENUM_PER], r[ENUM_PER];
     uint64_t bad = ~0ull;
-    enum_wave_rows(sh, tags, tile * ENUM_TILE, n, nv, v, r, bad);
+    enum_wave_rows(sh, d.tags, tile * ENUM_TILE, n, nv, v, r, bad);
     __syncthreads();
     if (threadIdx.x < nv) {
-        uint64_t run = chunk_base[(uint64_t)threadIdx.x * nchunks + tile / SCAN_CHUNK] + tile_counts[(uint64_t)threadIdx.x * ntiles + tile];
+        uint64_t run = enum_prefix(tile_counts, chunk_base, batch.ntiles, nchunks, threadIdx.x, T) -
+                       enum_prefix(tile_counts, chunk_base, batch.ntiles, nchunks, threadIdx.x, S);
 #pragma unroll
         for (int w = 0; w < ENUM_WAVES; w++) { start[w][threadIdx.x] = run; run += sh.wcnt[w][threadIdx.x]; }
     }
@@ -289,14 +342,25 @@ __global__ __launch_bounds__(ENUM_THREADS) void enum_write_kernel(const uint32_t
 
 // Status words: ZBRA_ERR_UNKNOWN_TAG with out_count = the first offending row and midpoint = its
 // tag, or ZBRA_OK with out_count = n.
-__global__ void enum_report_kernel(const uint32_t *__restrict__ tags, uint64_t n, const unsigned long long *first_bad_row,
-                                   zbra_dev_result *result) {
-    if (threadIdx.x != 0 || blockIdx.x != 0 || !result) return;
+// One lane per array.
+__global__ void enum_report_kernel(EnumBatch batch, const unsigned long long *first_bad_row, zbra_dev_result *results) {
+    const uint32_t a = blockIdx.x * blockDim.x + threadIdx.x;
+    if (a >= batch.nd || !results) return;
+    const zbra_enum_desc d = batch.arrays[a];
     zbra_dev_result res;
-    res.status = ZBRA_OK; res.width = 0; res.out_count = n; res.midpoint = 0; res.packed_len = 0;
-    const unsigned long long bad = *first_bad_row;
-    if (bad != ~0ull) { res.status = ZBRA_ERR_UNKNOWN_TAG; res.out_count = bad; res.midpoint = (int64_t)tags[bad]; }
-    *result = res;
+    res.status = ZBRA_OK; res.width = 0; res.out_count = d.n; res.midpoint = 0; res.packed_len = 0;
+    const unsigned long long bad = first_bad_row[a];
+    if (bad != ~0ull) { res.status = ZBRA_ERR_UNKNOWN_TAG; res.out_count = bad; res.midpoint = (int64_t)d.tags[bad]; }
+    results[a] = res;
+}
+
+// tile -> array table of a submission and the arrays' "no unknown tag seen" words.  One workgroup per array.
+__global__ __launch_bounds__(256) void enum_map_kernel(EnumBatch batch, uint32_t *__restrict__ tile_map, unsigned long long *first_bad_row) {
+    const uint32_t a = blockIdx.x;
+    if (a >= batch.nd) return;
+    if (threadIdx.x == 0) first_bad_row[a] = ~0ull;
+    if (batch.nd > 1)
+        for (uint64_t t = batch.tile_start[a] + threadIdx.x; t < batch.tile_start[a + 1]; t += blockDim.x) tile_map[t] = a;
 }
 
 }  // namespace zbra

@@ -9,6 +9,12 @@
 // the tile sums, and a second decode that scans inside the tile and stores the offsets.  HBM traffic is two
 // reads of the packed bytes and one write of 8 B per value; decoding the lengths first and
 // scanning them afterwards would write, read and write 8 B per value.
+//
+// A submission holds any number of independent lengths arrays (the Binary, Array and Nested
+// columns of one Block, or of many): tile T of the submission belongs to array a = tile_map[T] and
+// is that array's tile T - tile_start[a], exactly as in the batched decode.  The tile sums of ALL
+// arrays are scanned as one sequence; array a's running sum starts at zero because its tiles
+// subtract the scanned value of the array's first tile (wrapping arithmetic makes that exact).
 #pragma once
 #include "zbra_decode.hpp"
 
@@ -98,12 +104,20 @@ __device__ __forceinline__ uint64_t wave_sum_u64(uint64_t v) {
 // one dword ahead for the value that straddles the end.  No LDS, no barriers: a wave's life is one
 // load latency and the waves of a SIMD overlap theirs freely.
 constexpr int OFF_SUM_WAVES = 4;  // tiles (= waves) per workgroup
-__global__ __launch_bounds__(64 * OFF_SUM_WAVES) void offsets_sums_kernel(const DecodePlan *__restrict__ plan, uint64_t *__restrict__ tile_sums) {
-    const DecodePlan p = *plan;
+__global__ __launch_bounds__(64 * OFF_SUM_WAVES) void offsets_sums_kernel(const DecodePlan *__restrict__ plans, const uint64_t *__restrict__ tile_start,
+                                                                          const uint32_t *__restrict__ tile_map, uint32_t nd, uint64_t ntiles,
+                                                                          uint64_t *__restrict__ tile_sums) {
     const uint32_t lane = threadIdx.x & 63u;
-    const uint64_t t = (uint64_t)blockIdx.x * OFF_SUM_WAVES + (threadIdx.x >> 6);
+    const uint64_t T = (uint64_t)blockIdx.x * OFF_SUM_WAVES + (threadIdx.x >> 6);
+    if (T >= ntiles) return;  // uniform within the wave
+    const uint32_t a = nd > 1 ? tile_map[T] : 0;
+    const DecodePlan p = plans[a];
+    const uint64_t t = T - tile_start[a];
     const uint64_t v0 = t * OFF_TILE;
-    if (v0 >= p.count) return;  // rejected or empty array, or past the last tile: uniform within the wave
+    if (v0 >= p.count) {  // a tile of a rejected array (its frame's count gave it tiles): nothing to add
+        if (lane == 0) tile_sums[T] = 0;
+        return;
+    }
     const uint64_t left = p.count - v0;
     const uint32_t nv = left < (uint64_t)OFF_TILE ? (uint32_t)left : (uint32_t)OFF_TILE;
     const uint32_t w = p.width;
@@ -141,7 +155,7 @@ __global__ __launch_bounds__(64 * OFF_SUM_WAVES) void offsets_sums_kernel(const 
         }
     }  // width byte 0: every delta is 0 (compression.rs:187-189)
     sum = wave_sum_u64(sum);
-    if (lane == 0) tile_sums[t] = sum + (uint64_t)nv * (uint64_t)p.midpoint;
+    if (lane == 0) tile_sums[T] = sum + (uint64_t)nv * (uint64_t)p.midpoint;
 }
 
 // 2. Exclusive scan of the tile sums in two levels: every workgroup scans one chunk of SCAN_CHUNK
@@ -165,10 +179,9 @@ __device__ __forceinline__ uint64_t block_exclusive_scan_1024(uint64_t x, uint64
     *total = all;
     return before + inc - x;
 }
-__global__ __launch_bounds__(SCAN_CHUNK) void offsets_scan_chunks_kernel(const DecodePlan *__restrict__ plan, uint64_t *__restrict__ tile_sums,
+__global__ __launch_bounds__(SCAN_CHUNK) void offsets_scan_chunks_kernel(uint64_t ntiles, uint64_t *__restrict__ tile_sums,
                                                                           uint64_t *__restrict__ chunk_base) {
     __shared__ uint64_t wtot[SCAN_CHUNK / 64];
-    const uint64_t ntiles = (plan->count + OFF_TILE - 1) / OFF_TILE;
     const uint64_t t = (uint64_t)blockIdx.x * SCAN_CHUNK + threadIdx.x;
     if ((uint64_t)blockIdx.x * SCAN_CHUNK >= ntiles) return;  // uniform
     const uint64_t x = t < ntiles ? tile_sums[t] : 0;
@@ -177,10 +190,8 @@ __global__ __launch_bounds__(SCAN_CHUNK) void offsets_scan_chunks_kernel(const D
     if (t < ntiles) tile_sums[t] = ex;
     if (threadIdx.x == 0) chunk_base[blockIdx.x] = total;
 }
-__global__ __launch_bounds__(SCAN_CHUNK) void offsets_scan_totals_kernel(const DecodePlan *__restrict__ plan, uint64_t *__restrict__ chunk_base) {
+__global__ __launch_bounds__(SCAN_CHUNK) void offsets_scan_totals_kernel(uint64_t nchunks, uint64_t *__restrict__ chunk_base) {
     __shared__ uint64_t wtot[SCAN_CHUNK / 64];
-    const uint64_t ntiles = (plan->count + OFF_TILE - 1) / OFF_TILE;
-    const uint64_t nchunks = (ntiles + SCAN_CHUNK - 1) / SCAN_CHUNK;
     uint64_t carry = 0;
     for (uint64_t c0 = 0; c0 < nchunks; c0 += SCAN_CHUNK) {  // uniform trip count
         const uint64_t c = c0 + threadIdx.x;
@@ -197,21 +208,28 @@ __global__ __launch_bounds__(SCAN_CHUNK) void offsets_scan_totals_kernel(const D
 // of four and its two 16-byte stores are aligned whenever `offsets` is (writing the inclusive
 // prefixes to v0 + j + 1 instead straddles every 16-byte word and cost a third more time).
 // offsets[0] = 0 falls out; offsets[count] is written by the lane that holds the last value.
-// `chunk_base[c]` is the sum of the tiles before chunk c of SCAN_CHUNK tiles and `tile_sums[t]` the
-// sum of the earlier tiles of t's own chunk.
-__global__ __launch_bounds__(OFF_THREADS) void offsets_write_kernel(const DecodePlan *__restrict__ plan, const uint64_t *__restrict__ tile_sums,
-                                                                     const uint64_t *__restrict__ chunk_base, uint64_t *__restrict__ offsets, uint32_t reverse) {
+// `chunk_base[c]` is the sum of the submission's tiles before chunk c of SCAN_CHUNK tiles and
+// `tile_sums[T]` the sum of the earlier tiles of T's own chunk; the array's offsets (plan.out) start
+// at zero: what the scan holds for the array's first tile is subtracted.
+__global__ __launch_bounds__(OFF_THREADS) void offsets_write_kernel(const DecodePlan *__restrict__ plans, const uint64_t *__restrict__ tile_start,
+                                                                     const uint32_t *__restrict__ tile_map, uint32_t nd,
+                                                                     const uint64_t *__restrict__ tile_sums, const uint64_t *__restrict__ chunk_base,
+                                                                     uint32_t reverse) {
     __shared__ __attribute__((aligned(16))) uint32_t lds[lds_dwords<OFF_TILE>()];
     __shared__ __attribute__((aligned(16))) u64x2 turn[OFF_WAVES][64 * OFF_PER / 2];  // a wave's 256 offsets
     __shared__ uint64_t wtot[OFF_WAVES];
-    const DecodePlan p = *plan;
-    if (p.count == 0) {  // empty or rejected: the running sum of nothing
-        if (blockIdx.x == 0 && threadIdx.x == 0) offsets[0] = 0;  // whichever tile that is
-        return;
-    }
     // back to front when the packed bytes are more than the cache holds: what the sums pass read
     // last is what is still there (2^29 lengths of width 6: 1.277 -> 1.122 ms)
-    const uint64_t tile = reverse ? gridDim.x - 1 - blockIdx.x : blockIdx.x;
+    const uint64_t T = reverse ? gridDim.x - 1 - blockIdx.x : blockIdx.x;
+    const uint32_t a = nd > 1 ? tile_map[T] : 0;
+    const DecodePlan p = plans[a];
+    const uint64_t S = tile_start[a];
+    const uint64_t tile = T - S;
+    uint64_t *offsets = (uint64_t *)p.out;
+    if (p.count == 0) {  // rejected on the device (its frame's count gave it tiles): the running sum of nothing
+        if (tile == 0 && threadIdx.x == 0) offsets[0] = 0;
+        return;
+    }
     const uint64_t v0 = tile * OFF_TILE;
     if (v0 >= p.count) return;  // uniform
     const uint64_t left = p.count - v0;
@@ -236,7 +254,7 @@ __global__ __launch_bounds__(OFF_THREADS) void offsets_write_kernel(const Decode
     }
     if (lane == 63) wtot[wave] = inc;
     __syncthreads();
-    uint64_t run = chunk_base[tile / SCAN_CHUNK] + tile_sums[tile] + inc - mine;
+    uint64_t run = (chunk_base[T / SCAN_CHUNK] + tile_sums[T]) - (chunk_base[S / SCAN_CHUNK] + tile_sums[S]) + inc - mine;
     for (uint32_t k = 0; k < wave; k++) run += wtot[k];
     uint64_t o[OFF_PER + 1];
 #pragma unroll
@@ -266,6 +284,12 @@ __global__ __launch_bounds__(OFF_THREADS) void offsets_write_kernel(const Decode
         for (int k = 0; k < OFF_PER; k++)
             if (j + k + 1 == nv) out[k + 1] = o[k + 1];
     }
+}
+
+// Arrays whose frame says count 0 have no tile: their one offset is written here (one lane per array).
+__global__ void offsets_empty_kernel(const zbra_array_desc *__restrict__ descs, uint32_t nd) {
+    const uint32_t a = blockIdx.x * blockDim.x + threadIdx.x;
+    if (a < nd && descs[a].count == 0 && descs[a].out) ((uint64_t *)descs[a].out)[0] = 0;
 }
 
 }  // namespace zbra

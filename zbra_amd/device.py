@@ -8,7 +8,7 @@ import ctypes as C
 import torch
 
 from . import _lib
-from ._lib import ArrayDesc, DevResult, EncodeDesc, lib
+from ._lib import ArrayDesc, DevResult, EncodeDesc, EnumDesc, lib
 from .compression import _raise
 
 RESULT_BYTES = C.sizeof(DevResult)  # 32
@@ -85,6 +85,35 @@ def enum_rows_dev(tags: torch.Tensor, variant_tags, variant: torch.Tensor, rank:
     assert counts.is_cuda and counts.element_size() == 8 and counts.numel() >= len(variant_tags)
     st = lib.zbra_hip_enum_rows_dev(tags.data_ptr(), n, vt, len(variant_tags), variant.data_ptr(), rank.data_ptr(), counts.data_ptr(),
                                     result.data_ptr() if result is not None else None, _stream_handle(stream))
+    if st:
+        _raise(st)
+
+
+def decode_offsets_batch_dev(descs, results: torch.Tensor = None, stream=None):
+    """zbra_hip_decode_offsets_batch_dev: many lengths arrays, each decoded straight into its own
+    running sum, in one submission.  descs from make_descs(): `out` of array i is the device address
+    of count_i + 1 eight-byte words, kind ELEM_I64."""
+    st = lib.zbra_hip_decode_offsets_batch_dev(descs, len(descs), results.data_ptr() if results is not None else None,
+                                               _stream_handle(stream))
+    if st:
+        _raise(st)
+
+
+def enum_rows_batch_dev(arrays, variant_tags, results: torch.Tensor = None, stream=None):
+    """zbra_hip_enum_rows_batch_dev: the Enum row split of many tag arrays that share one variant
+    list, in one submission.  arrays: sequence of (tags, variant, rank, counts) CUDA tensors as in
+    enum_rows_dev."""
+    arrays = list(arrays)
+    descs = (EnumDesc * max(1, len(arrays)))()
+    for i, (tags, variant, rank, counts) in enumerate(arrays):
+        n = tags.numel()
+        assert tags.is_cuda and tags.element_size() == 4 and variant.element_size() == 4 and rank.element_size() == 8
+        assert variant.numel() >= n and rank.numel() >= n and counts.element_size() == 8 and counts.numel() >= len(variant_tags)
+        descs[i].tags, descs[i].n = tags.data_ptr(), n
+        descs[i].variant, descs[i].rank, descs[i].counts = variant.data_ptr(), rank.data_ptr(), counts.data_ptr()
+    vt = (C.c_uint32 * max(1, len(variant_tags)))(*[int(t) & 0xFFFFFFFF for t in variant_tags])
+    st = lib.zbra_hip_enum_rows_batch_dev(descs, len(arrays), vt, len(variant_tags), results.data_ptr() if results is not None else None,
+                                          _stream_handle(stream))
     if st:
         _raise(st)
 
