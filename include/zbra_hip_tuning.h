@@ -27,7 +27,8 @@ int zbra_tuning_set_launch_limit(uint64_t work_items);
 int zbra_tuning_set_decode_warm(uint64_t chunk_bytes, uint32_t max_bits, uint64_t min_bytes);
 
 /* Decode tile kernel shape: values per tile, threads per workgroup, nt (bit 0: nontemporal loads,
- * bit 1: nontemporal stores), direct (LDS-free reads), xcd (tile order: 0 plain, 1 chunked, 2 chosen
+ * bit 1: nontemporal stores), direct (0 = LDS image filled through registers, 1 = LDS-free reads, 2 = two
+ * tiles per workgroup whose packed bytes are brought in by LDS-DMA; 2048 x 512 only), xcd (tile order: 0 plain, 1 chunked, 2 chosen
  * by the submission's bits per value, >= 4 groups of that many tiles).  Returns 1 for a shape the
  * library was not built with. */
 int zbra_tuning_set_decode_variant(int tile, int threads, int nt, int direct, int xcd);

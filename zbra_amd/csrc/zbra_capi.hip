@@ -106,12 +106,21 @@ static void launch_decode_t(const DecodeConfig &c, hipStream_t stream, const Dec
     for (uint64_t done = 0; done < all_tiles; done += per) {
         const uint64_t base = first_tile + done;
         const uint64_t ntiles = all_tiles - done < per ? all_tiles - done : per;
+        if constexpr (DT == 2048 && TH == 512) {
+            if (c.direct == 2) {  // experimental shape: two tiles per workgroup, packed bytes by LDS-DMA
+                const uint64_t npairs = (ntiles + 1) / 2;
+                const uint32_t xp = npairs >= 64 ? want : 0u;
+                if (c.nt & 1) hipLaunchKernelGGL((decode_tiles_dma_kernel<DT, TH, 3>), dim3((unsigned)npairs), dim3(TH), 0, stream, plans, ts, tmap, nd, base, ntiles, xp);
+                else hipLaunchKernelGGL((decode_tiles_dma_kernel<DT, TH, 2>), dim3((unsigned)npairs), dim3(TH), 0, stream, plans, ts, tmap, nd, base, ntiles, xp);
+                continue;
+            }
+        }
         const unsigned grid = grid_for(ntiles, c.grid_cap);
         const dim3 g(grid), b(TH);
         const uint32_t x = ((uint64_t)grid == ntiles && ntiles >= 64) ? want : 0u;
 #define ZBRA_LAUNCH_DECODE(NTV, DIR) \
     hipLaunchKernelGGL((decode_tiles_kernel<DT, TH, NTV, DIR>), g, b, 0, stream, plans, ts, tmap, nd, base, ntiles, x)
-        switch ((c.nt & 3) * 2 + (c.direct ? 1 : 0)) {
+        switch ((c.nt & 3) * 2 + (c.direct == 1 ? 1 : 0)) {
             case 0: ZBRA_LAUNCH_DECODE(0, false); break;
             case 1: ZBRA_LAUNCH_DECODE(0, true); break;
             case 2: ZBRA_LAUNCH_DECODE(1, false); break;
@@ -153,7 +162,7 @@ struct Tuning {
 static bool apply_variant(Tuning &t, int tile, int th, int n, int d) {
     for (const DecodeShape &sh : kDecodeShapes)
         if (sh.tile == tile && sh.threads == th) {
-            t.decode.tile = tile; t.decode.threads = th; t.decode.nt = n & 3; t.decode.direct = d != 0;
+            t.decode.tile = tile; t.decode.threads = th; t.decode.nt = n & 3; t.decode.direct = d;  // 0 LDS image, 1 LDS-free, 2 LDS-DMA pairs
             t.decode_fn = sh.fn;
             return true;
         }

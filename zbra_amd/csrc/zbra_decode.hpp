@@ -470,4 +470,123 @@ __global__ __launch_bounds__(TH) void decode_tiles_kernel(const DecodePlan *__re
     }
 }
 
+// ---- experimental shape: two tiles per workgroup, packed bytes brought in by LDS-DMA ----------
+//
+// What holds the tile kernel above below the chip's copy rate is, by its counters, the time a wave
+// waits for its few packed bytes before it can store.  This shape asks for the packed bytes of TWO
+// tiles at once with global_load_lds_dwordx4 (the load writes LDS itself: no registers hold the
+// tile in flight, and the wave is free to go on), decodes the first tile as soon as ITS bytes have
+// landed and the second behind it.  The waits are counted by hand: vector-memory operations of a
+// wave (loads, LDS-DMA, stores) retire in issue order, so `s_waitcnt vmcnt(N)` with N = the
+// operations issued AFTER a tile's DMA returns when that DMA has landed and leaves the younger
+// operations (the other tile's DMA, the first tile's stores) in flight.  A compiler-inserted
+// vmcnt(0) would also wait for the first tile's 16 KiB of stores, which is what made every
+// register-prefetch shape of this kernel slower.  N must never exceed what was really issued (a
+// wait that is too weak reads stale LDS), so it is only above zero where the count is exact: this
+// wave's own DMA instructions, and the two store instructions of a FULL packed tile.
+// Selected with zbra_tuning_set_decode_variant(2048, 512, nt, 2, xcd); not the default (see the
+// measurements in DESIGN.md).
+
+// One wave-instruction: lanes [0, 64) copy 16 bytes each from their own global address to
+// lds_dst + 16 * lane (lds_dst is a wave-uniform LDS byte address).  M0 carries the LDS base; it
+// is saved and restored inside the statement because the compiler does not expect it to change.
+template <int NT>
+__device__ __forceinline__ void glds16(uintptr_t gsrc, uint32_t lds_dst) {
+    unsigned keep;
+    if constexpr (NT & 1)
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off nt\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+    else
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+
+// Waits until at most n of this wave's vector-memory operations are outstanding, then for the
+// workgroup.  n is wave-uniform and small.
+__device__ __forceinline__ void wait_vm_then_barrier(uint32_t n) {
+    switch (n) {
+        case 0: asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory"); break;
+        case 1: asm volatile("s_waitcnt vmcnt(1) lgkmcnt(0)\n\ts_barrier" ::: "memory"); break;
+        case 2: asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)\n\ts_barrier" ::: "memory"); break;
+        case 3: asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)\n\ts_barrier" ::: "memory"); break;
+        default: asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)\n\ts_barrier" ::: "memory"); break;
+    }
+}
+
+struct DmaTile {
+    DecodePlan p;
+    uint64_t v0;
+    uint32_t nv, tv;     // values in this tile (0 = nothing to do), values in a full tile of its kind
+    uint32_t base_bits;  // of the tile's first value from the start of its LDS image
+    uint32_t issued;     // DMA instructions this wave issued for it
+    bool packed;
+};
+
+template <int DT, int TH, int NT>
+__global__ __launch_bounds__(TH) void decode_tiles_dma_kernel(const DecodePlan *__restrict__ plans, const uint64_t *__restrict__ tile_start,
+                                                              const uint32_t *__restrict__ tile_map, uint32_t nd, uint64_t tile_base,
+                                                              uint64_t ntiles, uint32_t xcd_chunked) {
+    constexpr int BUF = (lds_dwords<2 * DT>() + 255) / 256 * 256;  // whole 1-KiB wave pieces
+    __shared__ __attribute__((aligned(1024))) uint32_t lds[2][BUF];
+    const uint64_t npairs = (ntiles + 1) >> 1;  // gridDim.x == npairs
+    const uint64_t pr = xcd_chunked == 1 ? xcd_chunked_tile(blockIdx.x, npairs) : xcd_chunked ? xcd_grouped_tile(blockIdx.x, npairs, xcd_chunked) : blockIdx.x;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63u;
+    DmaTile t[2];
+#pragma unroll
+    for (int q = 0; q < 2; q++) {
+        DmaTile &x = t[q];
+        x.nv = 0; x.issued = 0; x.packed = false; x.base_bits = 0; x.v0 = 0; x.tv = DT;
+        const uint64_t i = 2 * pr + q;
+        if (i >= ntiles) continue;  // uniform
+        const uint64_t T = tile_base + i;
+        const uint32_t a = nd > 1 ? tile_map[T] : 0;
+        x.p = plans[a];
+        x.tv = x.p.kind == ZBRA_ELEM_U32 ? 2 * DT : DT;
+        x.v0 = (T - tile_start[a]) * x.tv;
+        if (x.v0 >= x.p.count) continue;  // rejected or empty array
+        const uint64_t left = x.p.count - x.v0;
+        x.nv = left < (uint64_t)x.tv ? (uint32_t)left : x.tv;
+        x.packed = x.p.width - 1u < 31u;
+        if (x.packed) {
+            const PackedSpan sp = packed_span(x.p, x.v0, x.nv);
+            x.base_bits = sp.base_bits;
+            const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint32_t *)&lds[q][0];
+            for (uint32_t c0 = wave * 64u; c0 < sp.nchunks; c0 += TH) {  // uniform trip count within the wave
+                if (c0 + lane < sp.nchunks) glds16<NT>(sp.A0 + (uintptr_t)(c0 + lane) * 16, __builtin_amdgcn_readfirstlane(lds_base + c0 * 16u));
+                x.issued++;
+            }
+        }
+    }
+    // first tile: its DMA is older than the second tile's, which stays in flight
+    if (t[0].nv) {
+        if (t[0].packed) {
+            wait_vm_then_barrier(t[1].issued);
+            if (t[0].p.kind == ZBRA_ELEM_U32) packed_extract<2 * DT, TH, NT>(t[0].p, t[0].v0, t[0].nv, t[0].base_bits, lds[0]);
+            else packed_extract<DT, TH, NT>(t[0].p, t[0].v0, t[0].nv, t[0].base_bits, lds[0]);
+        } else if (t[0].p.width == 0) {
+            tile_fill<TH>(t[0].p, t[0].v0, t[0].nv);
+        } else if (t[0].p.kind == ZBRA_ELEM_U32) {
+            tile_raw<2 * DT, TH, NT>(t[0].p, t[0].v0, t[0].nv);
+        } else {
+            tile_raw<DT, TH, NT>(t[0].p, t[0].v0, t[0].nv);
+        }
+    }
+    if (t[1].nv) {
+        if (t[1].packed) {
+            // behind the second tile's DMA this wave has issued exactly two stores when the first tile
+            // was a full packed one; anything else is not counted on
+            const bool exact = t[0].nv && t[0].packed && t[0].nv == t[0].tv;
+            wait_vm_then_barrier(exact ? 2u : 0u);
+            if (t[1].p.kind == ZBRA_ELEM_U32) packed_extract<2 * DT, TH, NT>(t[1].p, t[1].v0, t[1].nv, t[1].base_bits, lds[1]);
+            else packed_extract<DT, TH, NT>(t[1].p, t[1].v0, t[1].nv, t[1].base_bits, lds[1]);
+        } else if (t[1].p.width == 0) {
+            tile_fill<TH>(t[1].p, t[1].v0, t[1].nv);
+        } else if (t[1].p.kind == ZBRA_ELEM_U32) {
+            tile_raw<2 * DT, TH, NT>(t[1].p, t[1].v0, t[1].nv);
+        } else {
+            tile_raw<DT, TH, NT>(t[1].p, t[1].v0, t[1].nv);
+        }
+    }
+}
+
 }  // namespace zbra
