@@ -305,6 +305,29 @@ int zbra_hip_file_index(const uint8_t *image, size_t len, zbra_file_array *array
 int zbra_hip_file_decode(const uint8_t *image, size_t len, const zbra_file_array *arrays, size_t n, void *const *outs,
                          int *statuses);
 
+/* One .zbra image to decode on one device: the arguments of zbra_hip_file_decode plus the device. */
+typedef struct zbra_file_job {
+    int32_t device;                /* HIP device index the job runs on */
+    int32_t status;                /* out: what zbra_hip_file_decode returned for this job */
+    const uint8_t *image;          /* HOST memory */
+    uint64_t len;
+    const zbra_file_array *arrays; /* from zbra_hip_file_index */
+    uint64_t n;
+    void *const *outs;             /* HOST buffers, one per array */
+    int *statuses;                 /* may be NULL */
+} zbra_file_job;
+
+/* Whole files on several GPUs from ONE process: files (and Blocks) never exchange data
+ * (binary.rs:124-127, 167-171), so file f goes to device jobs[f].device and nothing is reduced.
+ * The call starts one host thread per distinct device; each sets its device and runs that device's
+ * jobs in the order given through the pipeline of zbra_hip_file_decode (pinned hipMemcpyAsync both
+ * ways, batched decode in between), all devices at once.  Returns when every job is done; the
+ * return value is the first non-OK jobs[i].status in job order.  A device index that does not
+ * exist gives that job ZBRA_ERR_INVALID_ARG without disturbing the others.  The pinned-memory copy
+ * workers of the process are raised to eight per device in use (never above the CPUs the process
+ * may run on). */
+int zbra_hip_file_decode_multi(zbra_file_job *jobs, size_t n_jobs);
+
 /* decompress_int_array / read_u32_array_compressed for `nd` arrays whose encoded bytes sit in
  * separate HOST buffers, as they do after the reference's read_exact into a fresh Vec per array
  * (binary.rs:648-654, 671-674): descs[i].data / .out are HOST pointers here, out holding

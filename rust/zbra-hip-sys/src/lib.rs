@@ -101,6 +101,19 @@ pub mod ffi {
     }
 
     #[repr(C)]
+    #[derive(Debug, Clone, Copy)]
+    pub struct zbra_file_job {
+        pub device: i32,
+        pub status: i32,
+        pub image: *const u8,
+        pub len: u64,
+        pub arrays: *const zbra_file_array,
+        pub n: u64,
+        pub outs: *const *mut c_void,
+        pub statuses: *mut c_int,
+    }
+
+    #[repr(C)]
     #[derive(Debug, Clone, Copy, Default)]
     pub struct zbra_file_info {
         pub schema_offset: u64,
@@ -157,6 +170,7 @@ pub mod ffi {
                                    err_offset: *mut usize) -> c_int;
         pub fn zbra_hip_file_decode(image: *const u8, len: usize, arrays: *const zbra_file_array, n: usize, outs: *const *mut c_void,
                                     statuses: *mut c_int) -> c_int;
+        pub fn zbra_hip_file_decode_multi(jobs: *mut zbra_file_job, n_jobs: usize) -> c_int;
         pub fn zbra_hip_decode_batch(descs: *const zbra_array_desc, nd: usize, statuses: *mut c_int) -> c_int;
         pub fn zbra_hip_encode_frames(descs: *const zbra_encode_desc, nd: usize, out: *mut u8, cap: usize, offsets: *mut u64,
                                       statuses: *mut c_int) -> c_int;

@@ -292,3 +292,45 @@ def test_frames_that_produce_nothing():
     back = zb.BinaryFile.from_bytes(bytes(img))
     assert back.blocks[0].table.column.values.size == 0
     assert np.array_equal(back.blocks[1].table.column.values, real)
+
+
+@pytest.mark.gpu
+def test_files_on_every_device_from_one_process():
+    """zbra_hip_file_decode_multi: one image per job, jobs dealt to the devices of the box round robin
+    (file f on GPU f mod N; one device here means every job runs there, one after another), plus a
+    job that names a device that does not exist: it alone fails, the others decode exactly."""
+    import ctypes as C
+    import torch
+    from zbra_amd import _lib
+    from zbra_amd import binary as zb
+    ndev = torch.cuda.device_count()
+    jobs_data = []
+    for f in range(5):
+        blocks = [zb.Block(n, _rich_table(zb, n, 300 + 10 * f + i)) for i, n in enumerate([3, 4097, 30001 + f])]
+        img = zb.BinaryFile("{}", blocks).to_bytes(OracleCodec)
+        want = []
+        for b in blocks:
+            _int_arrays_in_order(zb, b.table, want)
+        info, arrays = zb.file_index(img)
+        assert info.n_arrays == len(want)
+        outs = [np.full(arrays[k].count, 0x55, dtype=np.int64 if arrays[k].kind == _lib.ELEM_I64 else np.uint32) for k in range(info.n_arrays)]
+        jobs_data.append((np.frombuffer(img, dtype=np.uint8), arrays, outs, want, (C.c_void_p * len(outs))(*[o.ctypes.data for o in outs]),
+                          (C.c_int * len(outs))()))
+    jobs = (_lib.FileJob * (len(jobs_data) + 1))()
+    for f, (buf, arrays, outs, want, ptrs, statuses) in enumerate(jobs_data):
+        jobs[f].device, jobs[f].status = f % ndev, -1
+        jobs[f].image, jobs[f].len = buf.ctypes.data, buf.size
+        jobs[f].arrays, jobs[f].n = arrays, len(outs)
+        jobs[f].outs, jobs[f].statuses = ptrs, statuses
+    bad = len(jobs_data)
+    jobs[bad].device = ndev + 3
+    jobs[bad].image, jobs[bad].len, jobs[bad].n = jobs[0].image, jobs[0].len, 0
+    assert _lib.lib.zbra_hip_file_decode_multi(jobs, len(jobs)) == _lib.ERR_INVALID_ARG      # the first failing job's status
+    assert jobs[bad].status == _lib.ERR_INVALID_ARG
+    for f, (buf, arrays, outs, want, ptrs, statuses) in enumerate(jobs_data):
+        assert jobs[f].status == 0 and list(statuses) == [0] * len(outs), f
+        for k, (values, kind, role) in enumerate(want):
+            expect = values if kind == 0 else values.astype(np.uint32)
+            assert np.array_equal(outs[k], expect), (f, k)
+    assert _lib.lib.zbra_hip_file_decode_multi(None, 0) == 0
+    assert torch.cuda.current_device() == 0                     # the caller's own device is untouched

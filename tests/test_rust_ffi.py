@@ -22,13 +22,13 @@ TYPES = {
     "uint64_t": "u64", "const char *": "*const c_char", "void *": "*mut c_void", "const void *": "*const c_void",
     "void *const *": "*const *mut c_void", "const uint8_t *": "*const u8", "uint8_t *": "*mut u8", "const int64_t *": "*const i64",
     "int64_t *": "*mut i64", "const uint64_t *": "*const u64", "uint64_t *": "*mut u64", "const uint32_t *": "*const u32",
-    "uint32_t *": "*mut u32",
+    "uint32_t *": "*mut u32", "int32_t": "i32",
 }
-for _s in ("zbra_dev_result", "zbra_array_desc", "zbra_encode_desc", "zbra_enum_desc", "zbra_file_array", "zbra_file_info"):
+for _s in ("zbra_dev_result", "zbra_array_desc", "zbra_encode_desc", "zbra_enum_desc", "zbra_file_array", "zbra_file_info", "zbra_file_job"):
     TYPES[f"{_s} *"] = f"*mut {_s}"
     TYPES[f"const {_s} *"] = f"*const {_s}"
 SIZES = {"u32": 4, "u64": 8, "i64": 8, "*const u8": 8, "*mut u8": 8, "*mut c_void": 8, "*const c_void": 8, "*const u32": 8, "*mut u32": 8,
-         "*mut u64": 8}
+         "*mut u64": 8, "i32": 4, "*const zbra_file_array": 8, "*const *mut c_void": 8, "*mut c_int": 8}
 
 
 def _c_text():
@@ -102,7 +102,7 @@ def _rs_structs():
 
 def test_structs_have_the_same_fields_in_the_same_order():
     c, rs = _c_structs(), _rs_structs()
-    assert sorted(c) == ["zbra_array_desc", "zbra_dev_result", "zbra_encode_desc", "zbra_enum_desc", "zbra_file_array", "zbra_file_info"]
+    assert sorted(c) == ["zbra_array_desc", "zbra_dev_result", "zbra_encode_desc", "zbra_enum_desc", "zbra_file_array", "zbra_file_info", "zbra_file_job"]
     assert sorted(rs) == sorted(c)
     for name in c:
         assert rs[name] == c[name], name
@@ -112,7 +112,7 @@ def test_structs_have_the_same_fields_in_the_same_order():
     for name in c:
         assert re.search(r"#\[repr\(C\)\]\s*(#\[derive\([^\]]*\)\]\s*)?pub struct " + name + r"\b", text), name
     sizes = {n: sum(SIZES[t] for _, t in f) for n, f in rs.items()}
-    src = '#include <stdio.h>\n#include "zbra_hip.h"\nint main(void){printf("%zu %zu %zu %zu %zu %zu\\n", sizeof(zbra_array_desc), sizeof(zbra_dev_result), sizeof(zbra_encode_desc), sizeof(zbra_enum_desc), sizeof(zbra_file_array), sizeof(zbra_file_info)); return 0;}\n'
+    src = '#include <stdio.h>\n#include "zbra_hip.h"\nint main(void){printf("%zu %zu %zu %zu %zu %zu %zu\\n", sizeof(zbra_array_desc), sizeof(zbra_dev_result), sizeof(zbra_encode_desc), sizeof(zbra_enum_desc), sizeof(zbra_file_array), sizeof(zbra_file_info), sizeof(zbra_file_job)); return 0;}\n'
     exe = "/tmp/zbra_sizes_check"
     subprocess.run(["gcc", "-std=c99", "-I", os.path.join(ROOT, "include"), "-x", "c", "-", "-o", exe], input=src, text=True, check=True)
     got = [int(x) for x in subprocess.check_output([exe], text=True).split()]

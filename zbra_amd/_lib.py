@@ -47,6 +47,12 @@ class FileInfo(C.Structure):
                 ("end_offset", C.c_uint64)]
 
 
+class FileJob(C.Structure):
+    """zbra_file_job of include/zbra_hip.h."""
+    _fields_ = [("device", C.c_int32), ("status", C.c_int32), ("image", C.c_void_p), ("len", C.c_uint64),
+                ("arrays", C.POINTER(FileArray)), ("n", C.c_uint64), ("outs", C.POINTER(C.c_void_p)), ("statuses", C.POINTER(C.c_int))]
+
+
 _p, _sz = C.c_void_p, C.c_size_t
 _psz = C.POINTER(C.c_size_t)
 
@@ -82,6 +88,7 @@ SIGNATURES = {
     "zbra_hip_encode_frames_dev": (C.c_int, [C.POINTER(EncodeDesc), _sz, _p, _sz, _p, _p, _p]),
     "zbra_hip_encode_frames": (C.c_int, [C.POINTER(EncodeDesc), _sz, _p, _sz, C.POINTER(C.c_uint64), C.POINTER(C.c_int)]),
     "zbra_hip_file_index": (C.c_int, [_p, _sz, C.POINTER(FileArray), _sz, C.POINTER(FileInfo), _psz]),
+    "zbra_hip_file_decode_multi": (C.c_int, [C.POINTER(FileJob), _sz]),
     "zbra_hip_file_decode": (C.c_int, [_p, _sz, C.POINTER(FileArray), _sz, C.POINTER(C.c_void_p), C.POINTER(C.c_int)]),
 }
 

@@ -4,6 +4,7 @@
 
 #include <cstdio>
 #include <cstdlib>
+#include <algorithm>
 #include <atomic>
 #include <condition_variable>
 #include <cstring>
@@ -1631,6 +1632,37 @@ int zbra_hip_file_decode(const uint8_t *image, size_t len, const zbra_file_array
         items[i].out = outs[i]; items[i].kind = arrays[i].kind; items[i].reserved = 0;
     }
     return decode_host_batch(items.data(), n, statuses);
+}
+
+int zbra_hip_file_decode_multi(zbra_file_job *jobs, size_t n_jobs) {
+    if (n_jobs == 0) return ZBRA_OK;
+    if (!jobs) return ZBRA_ERR_INVALID_ARG;
+    int devices = 0;
+    ZBRA_TRY(zbra_hip_device_count(&devices));
+    if (devices == 0) return ZBRA_ERR_NO_DEVICE;
+    std::vector<int> used;  // distinct devices, in order of first appearance
+    for (size_t i = 0; i < n_jobs; i++) {
+        jobs[i].status = jobs[i].device < 0 || jobs[i].device >= devices ? ZBRA_ERR_INVALID_ARG : ZBRA_OK;
+        if (jobs[i].status == ZBRA_OK && std::find(used.begin(), used.end(), (int)jobs[i].device) == used.end()) used.push_back(jobs[i].device);
+    }
+    CopyWorkers::instance().ensure_threads(8 * (int)used.size());
+    // one host thread per device: the current device is per thread, and so are the device's
+    // context, streams and pinned rings (the calling thread's own current device is left as it is)
+    auto run_device = [&](int dev) {
+        const int st_dev = zbra_hip_set_device(dev);
+        for (size_t i = 0; i < n_jobs; i++) {
+            if (jobs[i].device != dev || jobs[i].status != ZBRA_OK) continue;
+            jobs[i].status = st_dev != ZBRA_OK ? st_dev
+                                               : zbra_hip_file_decode(jobs[i].image, (size_t)jobs[i].len, jobs[i].arrays, (size_t)jobs[i].n, jobs[i].outs,
+                                                                      jobs[i].statuses);
+        }
+    };
+    std::vector<std::thread> threads;
+    for (int dev : used) threads.emplace_back(run_device, dev);
+    for (std::thread &t : threads) t.join();
+    for (size_t i = 0; i < n_jobs; i++)
+        if (jobs[i].status != ZBRA_OK) return jobs[i].status;
+    return ZBRA_OK;
 }
 
 int zbra_hip_decode_batch(const zbra_array_desc *descs, size_t nd, int *statuses) {

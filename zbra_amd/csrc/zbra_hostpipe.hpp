@@ -75,7 +75,24 @@ class CopyWorkers {
         }
     }
 
-    int threads() const { return nthreads_; }
+    int threads() const { return nthreads_.load(); }
+
+    // Raises the number of worker threads to `want` (bounded by the CPUs the process may run on and by
+    // 64); never lowers it.  A reader that drives several devices at once needs as many memcpy
+    // workers per device as a reader of one device has, or the host side becomes the bound.
+    void ensure_threads(int want) {
+        if (std::getenv("ZBRA_HIP_HOST_THREADS")) return;  // the caller fixed the number
+        cpu_set_t set;
+        int cpus = 1;
+        if (sched_getaffinity(0, sizeof(set), &set) == 0) cpus = CPU_COUNT(&set);
+        if (want > cpus - 1) want = cpus - 1;
+        if (want > 64) want = 64;
+        std::lock_guard<std::mutex> g(grow_mu_);
+        while (nthreads_.load() < want) {
+            std::thread([this] { loop(); }).detach();
+            nthreads_.fetch_add(1);
+        }
+    }
 
    private:
     CopyWorkers() {
@@ -90,7 +107,7 @@ class CopyWorkers {
         }
         if (n < 0) n = 0;
         if (n > 64) n = 64;
-        nthreads_ = n;
+        nthreads_.store(n);
         for (int i = 0; i < n; i++) std::thread([this] { loop(); }).detach();
     }
 
@@ -123,7 +140,8 @@ class CopyWorkers {
     std::mutex mu_;
     std::condition_variable cv_;
     std::deque<Task> queue_;
-    int nthreads_ = 0;
+    std::atomic<int> nthreads_{0};
+    std::mutex grow_mu_;
 };
 
 // The pinned ring of one device context.  Used under the context's host_mu only.
