@@ -444,13 +444,22 @@ static int decode_offsets_batch_dev(DeviceCtx *ctx, const zbra_array_desc *descs
     if (!descs) return ZBRA_ERR_INVALID_ARG;
     uint64_t ntiles = 0, all_bytes = 0;
     bool any_empty = false;
+    // Widest packed width any array of the submission can have: an array whose header passes the
+    // checks has ceil(count * w / 8) payload bytes inside its len - 13, so w <= (len - 13) * 8 / count.
+    // It sizes the LDS images of the sums pass (narrow lengths arrays then leave room for more waves).
+    uint32_t wmax = 1;
     for (size_t i = 0; i < nd; i++) {
         const zbra_array_desc &d = descs[i];
         if (d.count > MAX_COUNT || d.kind != ZBRA_ELEM_I64 || !d.out || (d.len && !d.data)) return ZBRA_ERR_INVALID_ARG;
         ntiles += (d.count + OFF_TILE - 1) / OFF_TILE;
         all_bytes += d.len;
         any_empty = any_empty || d.count == 0;
+        if (d.count >= (uint64_t)OFF_TILE && d.len > 13) {  // shorter arrays have no full tile
+            const uint64_t w = ((d.len - 13) * 8 + d.count - 1) / d.count;
+            wmax = w >= 31 ? 31u : (uint32_t)w > wmax ? (uint32_t)w : wmax;
+        }
     }
+    const uint32_t image_dwords = offsets_image_dwords(wmax);
     // one workgroup per tile in the write pass: a longer table goes down in pieces (arrays are independent)
     const uint64_t most_tiles = launch_limit() / OFF_THREADS;
     if (nd > 1 && (ntiles > most_tiles || nd > MAX_BATCH_ARRAYS)) {
@@ -498,8 +507,15 @@ static int decode_offsets_batch_dev(DeviceCtx *ctx, const zbra_array_desc *descs
                                d_results, (const uint32_t *)nullptr);
         if (any_empty) hipLaunchKernelGGL(offsets_empty_kernel, dim3((unsigned)((nd + 255) / 256)), dim3(256), 0, stream, d_descs, (uint32_t)nd);
         if (ntiles) {
-            hipLaunchKernelGGL(offsets_sums_kernel, dim3((unsigned)((ntiles + OFF_SUM_WAVES - 1) / OFF_SUM_WAVES)), dim3(64 * OFF_SUM_WAVES), 0, stream,
-                               d_plans, d_ts, d_map, (uint32_t)nd, ntiles, tile_sums);
+            const uint64_t per_wg = (uint64_t)OFF_SUM_WAVES * OFF_SUM_TPW;
+#define ZBRA_LAUNCH_SUMS(WM)                                                                                                         \
+    hipLaunchKernelGGL((offsets_sums_kernel<WM>), dim3((unsigned)((ntiles + per_wg - 1) / per_wg)), dim3(64 * OFF_SUM_WAVES),          \
+                       (size_t)OFF_SUM_WAVES * image_dwords * sizeof(uint32_t), stream, d_plans, d_ts, d_map, (uint32_t)nd, ntiles, tile_sums, \
+                       image_dwords)
+            if (wmax <= 8) ZBRA_LAUNCH_SUMS(8);
+            else if (wmax <= 16) ZBRA_LAUNCH_SUMS(16);
+            else ZBRA_LAUNCH_SUMS(31);
+#undef ZBRA_LAUNCH_SUMS
             hipLaunchKernelGGL(offsets_scan_chunks_kernel, dim3((unsigned)nchunks), dim3(SCAN_CHUNK), 0, stream, ntiles, tile_sums, chunk_base);
             hipLaunchKernelGGL(offsets_scan_totals_kernel, dim3(1), dim3(SCAN_CHUNK), 0, stream, nchunks, chunk_base);
             // the write pass finds the packed bytes in the memory-side cache (256 MB) if the sums pass left them there:

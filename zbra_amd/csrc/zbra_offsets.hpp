@@ -98,31 +98,170 @@ __device__ __forceinline__ uint64_t wave_sum_u64(uint64_t v) {
     return v;
 }
 
+// Sum of the deltas of one FULL tile of packed width W, by one wave.  The pass is bound by its
+// vector instructions, so the extraction is made straight-line: lane l takes the tile's values
+// [32 l, 32 l + 32), which are exactly W dwords of the stream (32 * W bits), every field then sits
+// at a compile-time position of the lane's registers, and a value costs two bit-field extracts, an
+// exclusive-or and an add (a funnel shift more where it straddles two dwords).  The packed bytes
+// come in with the same coalesced 16-byte loads as before and are dealt to the lanes through a
+// wave-private LDS image; runs are one dword apart for even W (an odd stride in dwords: lanes then
+// hit different banks).  The tile starts at any byte of memory: the stream is brought to a dword
+// boundary by one funnel shift per dword (the shift, 0 / 8 / 16 / 24 bits, is the same for every
+// tile of an array).
+// Dwords of one wave's image for width w: 64 runs of w dwords, one dword apart for even w, and the dword behind them.
+__host__ __device__ constexpr uint32_t offsets_image_dwords(uint32_t w) { return 64u * (w + (w % 2 == 0 ? 1u : 0u)) + 8u; }
+
+
+// `ntl` consecutive FULL tiles of one array of packed width W, summed by one wave: sums[k] = sum of
+// the values of the k-th of them.  The packed bytes of tile k + 1 are asked for before tile k is
+// looked at, so only the first tile's load latency is waited for in full.
+template <int W>
+__device__ __forceinline__ void offsets_full_tiles_sums(const DecodePlan &p, uint64_t v0, uint32_t ntl, uint32_t *wl, uint64_t *__restrict__ sums) {
+    constexpr int STRIDE = W + (W % 2 == 0 ? 1 : 0);
+    constexpr int NCH = (16 * W + 1 + 63) / 64;  // 16-byte chunks per lane: a tile's 256 W bytes touch at most 16 W + 1 chunks
+    const uint32_t lane = threadIdx.x & 63u;
+    // every tile of an array starts at the same place of a 16-byte chunk (a tile is 256 W bytes)
+    const PackedSpan sp0 = packed_span(p, v0, OFF_TILE);
+    const uint32_t b0 = sp0.base_bits >> 5, r = sp0.base_bits & 31u;  // first dword of the tile inside its first chunk; bits into it
+    const uint32_t nchunks = sp0.nchunks;
+    auto load = [&](uint32_t k, u32x4 (&x)[NCH]) {
+        const uintptr_t A0 = sp0.A0 + (uintptr_t)k * (256u * W);
+#pragma unroll
+        for (int i = 0; i < NCH; i++) {
+            const uint32_t c = lane + 64u * i;
+            if (c < nchunks) x[i] = ld_stream<ZBRA_OFF_NT>(gptr<u32x4>(A0 + (uintptr_t)c * 16));
+        }
+    };
+    // D tiles' packed bytes are in flight per wave (in registers; the narrower the array, the more fit):
+    // with one tile ahead only, the waves of a CU had 40 KB of loads outstanding, too little for the
+    // latency of HBM (2^28 lengths of width 6: 87 us for this pass, most of it waiting).
+    constexpr int D = NCH <= 3 ? 4 : NCH <= 5 ? 2 : 1;
+    u32x4 buf[D][NCH];
+#pragma unroll
+    for (int j = 0; j < D; j++) {
+#pragma unroll
+        for (int i = 0; i < NCH; i++) buf[j][i] = u32x4{0, 0, 0, 0};
+        if ((uint32_t)j < ntl) load((uint32_t)j, buf[j]);
+    }
+    for (uint32_t k0 = 0; k0 < ntl; k0 += D) {  // uniform
+#pragma unroll
+      for (int j = 0; j < D; j++) {
+        const uint32_t k = k0 + (uint32_t)j;
+        if (k >= ntl) break;  // uniform
+        u32x4 cur[NCH];
+#pragma unroll
+        for (int i = 0; i < NCH; i++) cur[i] = buf[j][i];
+        if (k + D < ntl) load(k + D, buf[j]);
+        // this wave's reads of the image of the tile before are done before it is overwritten
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int i = 0; i < NCH; i++) {
+            const uint32_t c = lane + 64u * i;
+            const uint32_t x[4] = {cur[i].x, cur[i].y, cur[i].z, cur[i].w};
+#pragma unroll
+            for (int t = 0; t < 4; t++) {
+                const uint32_t jj = c * 4u + (uint32_t)t - b0;  // dword of the tile's stream; wraps for the dwords in front of it
+                if (c < nchunks && jj <= 64u * W) wl[jj + (STRIDE - W) * (jj / W)] = x[t];
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        uint32_t d[W + 1];
+#pragma unroll
+        for (int q = 0; q < W; q++) d[q] = wl[lane * STRIDE + q];
+        d[W] = wl[(lane + 1) * STRIDE];  // the next run's first dword (past the tile for the last lane: only used when r != 0, and then it was staged)
+        if (r) {  // uniform
+#pragma unroll
+            for (int q = 0; q < W; q++) d[q] = __builtin_amdgcn_alignbit(d[q + 1], d[q], r);
+        }
+        // 32 deltas of at most 2^(W-1) in magnitude: a 32-bit sum holds them up to W = 26
+        int32_t acc32 = 0;
+        int64_t acc64 = 0;
+#pragma unroll
+        for (int i = 0; i < 32; i++) {
+            const int bit = i * W, q = bit >> 5, off = bit & 31;
+            const uint32_t x = off + W <= 32 ? d[q] >> off : __builtin_amdgcn_alignbit(d[q + 1 <= W ? q + 1 : W], d[q], (uint32_t)off);
+            const uint32_t h = W > 1 ? (x >> 1) & ((1u << (W - 1)) - 1u) : 0u;
+            const int32_t delta = (int32_t)h ^ -(int32_t)(x & 1u);  // zig_zag_decode, compression.rs:101-111
+            if (W <= 26) acc32 += delta;
+            else acc64 += delta;
+        }
+        const uint64_t sum = wave_sum_u64((uint64_t)(W <= 26 ? (int64_t)acc32 : acc64));
+        if (lane == 0) sums[k] = sum + (uint64_t)OFF_TILE * (uint64_t)p.midpoint;
+      }
+    }
+}
+template <int W, int WMAX>
+__device__ __forceinline__ bool offsets_full_tiles_sums_from(uint32_t w, const DecodePlan &p, uint64_t v0, uint32_t ntl, uint32_t *wl, uint32_t room,
+                                                             uint64_t *__restrict__ sums) {
+    if constexpr (W > WMAX) {
+        return false;
+    } else {
+        if (w == (uint32_t)W) {
+            if (offsets_image_dwords(W) > room) return false;  // the launch sized the images for narrower arrays: the caller takes the generic form
+            offsets_full_tiles_sums<W>(p, v0, ntl, wl, sums);
+            return true;
+        }
+        return offsets_full_tiles_sums_from<W + 1, WMAX>(w, p, v0, ntl, wl, room, sums);
+    }
+}
+
 // 1. tile_sums[t] = sum of the tile's values.  The order of a sum does not matter, so nothing is
 // staged or transposed: one wave per tile, a lane takes whole 16-byte chunks of the packed bytes
 // (coalesced loads) and adds up the values that START in each of the chunk's four dwords, looking
 // one dword ahead for the value that straddles the end.  No LDS, no barriers: a wave's life is one
 // load latency and the waves of a SIMD overlap theirs freely.
-constexpr int OFF_SUM_WAVES = 4;  // tiles (= waves) per workgroup
+constexpr int OFF_SUM_WAVES = 4;  // waves per workgroup
+// Consecutive tiles one wave sums, one after the other.  A wave that lives for one tile of a narrow
+// array (a kilobyte or two of packed bytes) spends most of its life being launched and fetching its
+// plan: 2^28 lengths of width 6 are 131072 such waves.
+#ifndef ZBRA_OFF_SUM_TPW
+#define ZBRA_OFF_SUM_TPW 16
+#endif
+constexpr int OFF_SUM_TPW = ZBRA_OFF_SUM_TPW;
+// WMAX: widest array that takes the straight-line form in this instance.  The form keeps two tiles
+// of packed bytes and a lane's run in registers, W-dependent, and a kernel is allotted the registers
+// of its hungriest path: one instance for all 31 widths would run narrow arrays at the occupancy of
+// width 31.  The host picks the instance from the widest array of the submission.
+template <int WMAX>
 __global__ __launch_bounds__(64 * OFF_SUM_WAVES) void offsets_sums_kernel(const DecodePlan *__restrict__ plans, const uint64_t *__restrict__ tile_start,
                                                                           const uint32_t *__restrict__ tile_map, uint32_t nd, uint64_t ntiles,
-                                                                          uint64_t *__restrict__ tile_sums) {
+                                                                          uint64_t *__restrict__ tile_sums, uint32_t image_dwords) {
+    // image_dwords: LDS dwords per wave (the launch's dynamic LDS is OFF_SUM_WAVES times that), sized by
+    // the host for the widest array of the submission as its frame lengths bound it
+    extern __shared__ uint32_t images[];
     const uint32_t lane = threadIdx.x & 63u;
-    const uint64_t T = (uint64_t)blockIdx.x * OFF_SUM_WAVES + (threadIdx.x >> 6);
-    if (T >= ntiles) return;  // uniform within the wave
+    const uint64_t T0 = ((uint64_t)blockIdx.x * OFF_SUM_WAVES + (threadIdx.x >> 6)) * OFF_SUM_TPW;
+    if (T0 >= ntiles) return;  // uniform within the wave
+    {
+        // the wave's tiles are full packed tiles of ONE array (the usual case): the straight-line form
+        const uint64_t Tl = T0 + OFF_SUM_TPW <= ntiles ? T0 + OFF_SUM_TPW - 1 : ntiles - 1;
+        const uint32_t a = nd > 1 ? tile_map[T0] : 0;
+        if (nd == 1 || tile_map[Tl] == a) {
+            const DecodePlan p = plans[a];
+            const uint64_t t0 = T0 - tile_start[a], tl = Tl - tile_start[a];
+            if (p.width - 1u < 31u && (tl + 1) * OFF_TILE <= p.count &&
+                offsets_full_tiles_sums_from<1, WMAX>(p.width, p, t0 * OFF_TILE, (uint32_t)(tl - t0 + 1), images + (threadIdx.x >> 6) * image_dwords, image_dwords,
+                                                tile_sums + T0))
+                return;
+        }
+    }
+  for (uint64_t T = T0; T < T0 + OFF_SUM_TPW && T < ntiles; T++) {  // uniform within the wave
     const uint32_t a = nd > 1 ? tile_map[T] : 0;
     const DecodePlan p = plans[a];
     const uint64_t t = T - tile_start[a];
     const uint64_t v0 = t * OFF_TILE;
     if (v0 >= p.count) {  // a tile of a rejected array (its frame's count gave it tiles): nothing to add
         if (lane == 0) tile_sums[T] = 0;
-        return;
+        continue;
     }
     const uint64_t left = p.count - v0;
     const uint32_t nv = left < (uint64_t)OFF_TILE ? (uint32_t)left : (uint32_t)OFF_TILE;
     const uint32_t w = p.width;
     uint64_t sum = 0;  // of the deltas; the midpoints are added at the end
-    if (w - 1u < 31u) {
+    if (w - 1u < 31u) {  // a run of tiles with a ragged last one or of several arrays, or an image too small for this width
         const PackedSpan sp = packed_span(p, v0, nv);
         const uint32_t mask = (1u << w) - 1u;
         // n / w == (n * magic) >> 21 for n < 2^16: magic * w - 2^21 < w <= 31 and n * 31 < 2^21.
@@ -156,6 +295,7 @@ __global__ __launch_bounds__(64 * OFF_SUM_WAVES) void offsets_sums_kernel(const 
     }  // width byte 0: every delta is 0 (compression.rs:187-189)
     sum = wave_sum_u64(sum);
     if (lane == 0) tile_sums[T] = sum + (uint64_t)nv * (uint64_t)p.midpoint;
+  }
 }
 
 // 2. Exclusive scan of the tile sums in two levels: every workgroup scans one chunk of SCAN_CHUNK
