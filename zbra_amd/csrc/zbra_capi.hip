@@ -507,11 +507,13 @@ static int decode_offsets_batch_dev(DeviceCtx *ctx, const zbra_array_desc *descs
                                d_results, (const uint32_t *)nullptr);
         if (any_empty) hipLaunchKernelGGL(offsets_empty_kernel, dim3((unsigned)((nd + 255) / 256)), dim3(256), 0, stream, d_descs, (uint32_t)nd);
         if (ntiles) {
-            const uint64_t per_wg = (uint64_t)OFF_SUM_WAVES * OFF_SUM_TPW;
+            const uint64_t tpw_want = ntiles / OFF_SUM_MIN_WAVES;
+            const uint32_t tpw = tpw_want < 1 ? 1u : tpw_want > OFF_SUM_TPW_MAX ? OFF_SUM_TPW_MAX : (uint32_t)tpw_want;
+            const uint64_t per_wg = (uint64_t)OFF_SUM_WAVES * tpw;
 #define ZBRA_LAUNCH_SUMS(WM)                                                                                                         \
     hipLaunchKernelGGL((offsets_sums_kernel<WM>), dim3((unsigned)((ntiles + per_wg - 1) / per_wg)), dim3(64 * OFF_SUM_WAVES),          \
                        (size_t)OFF_SUM_WAVES * image_dwords * sizeof(uint32_t), stream, d_plans, d_ts, d_map, (uint32_t)nd, ntiles, tile_sums, \
-                       image_dwords)
+                       image_dwords, tpw)
             if (wmax <= 8) ZBRA_LAUNCH_SUMS(8);
             else if (wmax <= 16) ZBRA_LAUNCH_SUMS(16);
             else ZBRA_LAUNCH_SUMS(31);

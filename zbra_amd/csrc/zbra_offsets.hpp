@@ -217,10 +217,10 @@ constexpr int OFF_SUM_WAVES = 4;  // waves per workgroup
 // Consecutive tiles one wave sums, one after the other.  A wave that lives for one tile of a narrow
 // array (a kilobyte or two of packed bytes) spends most of its life being launched and fetching its
 // plan: 2^28 lengths of width 6 are 131072 such waves.
-#ifndef ZBRA_OFF_SUM_TPW
-#define ZBRA_OFF_SUM_TPW 16
-#endif
-constexpr int OFF_SUM_TPW = ZBRA_OFF_SUM_TPW;
+// The launch says how many (tiles_per_wave): as many as leave the chip enough waves, 16 at most; a
+// single array of 2^22 lengths keeps one tile per wave (its 2048 waves would otherwise be 128).
+constexpr uint32_t OFF_SUM_TPW_MAX = 16;
+constexpr uint64_t OFF_SUM_MIN_WAVES = 8192;  // about what the chip holds at once
 // WMAX: widest array that takes the straight-line form in this instance.  The form keeps two tiles
 // of packed bytes and a lane's run in registers, W-dependent, and a kernel is allotted the registers
 // of its hungriest path: one instance for all 31 widths would run narrow arrays at the occupancy of
@@ -228,16 +228,17 @@ constexpr int OFF_SUM_TPW = ZBRA_OFF_SUM_TPW;
 template <int WMAX>
 __global__ __launch_bounds__(64 * OFF_SUM_WAVES) void offsets_sums_kernel(const DecodePlan *__restrict__ plans, const uint64_t *__restrict__ tile_start,
                                                                           const uint32_t *__restrict__ tile_map, uint32_t nd, uint64_t ntiles,
-                                                                          uint64_t *__restrict__ tile_sums, uint32_t image_dwords) {
+                                                                          uint64_t *__restrict__ tile_sums, uint32_t image_dwords,
+                                                                          uint32_t tiles_per_wave) {
     // image_dwords: LDS dwords per wave (the launch's dynamic LDS is OFF_SUM_WAVES times that), sized by
     // the host for the widest array of the submission as its frame lengths bound it
     extern __shared__ uint32_t images[];
     const uint32_t lane = threadIdx.x & 63u;
-    const uint64_t T0 = ((uint64_t)blockIdx.x * OFF_SUM_WAVES + (threadIdx.x >> 6)) * OFF_SUM_TPW;
+    const uint64_t T0 = ((uint64_t)blockIdx.x * OFF_SUM_WAVES + (threadIdx.x >> 6)) * tiles_per_wave;
     if (T0 >= ntiles) return;  // uniform within the wave
     {
         // the wave's tiles are full packed tiles of ONE array (the usual case): the straight-line form
-        const uint64_t Tl = T0 + OFF_SUM_TPW <= ntiles ? T0 + OFF_SUM_TPW - 1 : ntiles - 1;
+        const uint64_t Tl = T0 + tiles_per_wave <= ntiles ? T0 + tiles_per_wave - 1 : ntiles - 1;
         const uint32_t a = nd > 1 ? tile_map[T0] : 0;
         if (nd == 1 || tile_map[Tl] == a) {
             const DecodePlan p = plans[a];
@@ -248,7 +249,7 @@ __global__ __launch_bounds__(64 * OFF_SUM_WAVES) void offsets_sums_kernel(const 
                 return;
         }
     }
-  for (uint64_t T = T0; T < T0 + OFF_SUM_TPW && T < ntiles; T++) {  // uniform within the wave
+  for (uint64_t T = T0; T < T0 + tiles_per_wave && T < ntiles; T++) {  // uniform within the wave
     const uint32_t a = nd > 1 ? tile_map[T] : 0;
     const DecodePlan p = plans[a];
     const uint64_t t = T - tile_start[a];
