@@ -1,6 +1,5 @@
 #!/bin/bash
-# The per-round set of kernel-level profiles that DESIGN.md quotes, beyond what profile_bench.sh
-# collects: per-kernel times of the other configurations and of the widened rows, and the encode of a
+# Kernel-level profiles beyond what profile_bench.sh collects: per-kernel times of the other configurations and of the widened rows, and the encode of a
 # wide (25-bit) and a full-range (64-bit) column with HBM bytes per kernel.
 # Usage: scripts/collect_profiles.sh r03   (writes gpurun_out/<tag>_*.txt; copy what is to be kept into profiles/)
 tag=${1:-r03}

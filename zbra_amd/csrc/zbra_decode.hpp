@@ -484,8 +484,11 @@ __global__ __launch_bounds__(TH) void decode_tiles_kernel(const DecodePlan *__re
 // register-prefetch shape of this kernel slower.  N must never exceed what was really issued (a
 // wait that is too weak reads stale LDS), so it is only above zero where the count is exact: this
 // wave's own DMA instructions, and the two store instructions of a FULL packed tile.
-// Selected with zbra_tuning_set_decode_variant(2048, 512, nt, 2, xcd); not the default (see the
-// measurements in DESIGN.md).
+// Selected with zbra_tuning_set_decode_variant(2048, 512, nt, 2, xcd); not the default: timed cold
+// against the one-tile kernel it lost at every width (u32 tags at 2^29 rows 0.469 against 0.407 ms,
+// width 7 0.236 / 0.209, the 2^28-row width-12 column 0.440 / 0.424, width 26 0.256 / 0.244): with 32
+// waves per CU all loading, the workgroups' overlap already hides the packed bytes' latency, and a
+// workgroup that holds two tiles halves the independent workgroups whose stores interleave.
 
 // One wave-instruction: lanes [0, 64) copy 16 bytes each from their own global address to
 // lds_dst + 16 * lane (lds_dst is a wave-uniform LDS byte address).  M0 carries the LDS base; it
