@@ -44,3 +44,17 @@ def test_every_device_from_one_process():
     p = subprocess.run([MULTI], capture_output=True, text=True, timeout=300)
     assert p.returncode == 0, p.stdout + p.stderr
     assert " 0 failures" in p.stdout and "device 0 at " in p.stdout
+
+
+HOST_PATHS = os.path.join(ROOT, "tests", "c", "test_host_paths")
+
+
+@pytest.mark.gpu
+def test_threaded_host_paths_from_c():
+    """tests/c/test_host_paths.c: the two-lane write path over several rounds at three capacities and a
+    failing one, and zbra_hip_file_decode_multi with two jobs per device, against the oracle."""
+    if not os.path.exists(HOST_PATHS):
+        subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "tests", "c")])
+    p = subprocess.run([HOST_PATHS], capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stdout + p.stderr
+    assert " 0 failures" in p.stdout

@@ -91,6 +91,49 @@ def test_host_frames_capacity(env):
     assert (out[len(want):] == 0xAB).all()
 
 
+def test_host_frames_many_rounds_and_capacities(env):
+    """Enough values (about 270 MB) that the host write path cuts them into several rounds on its two
+    lanes, with a second thread copying frames back while the next round goes up.  The frames must be
+    the oracle's whatever the capacity allows the rounds to do: run ahead (generous capacity), wait
+    for each other (exact capacity), or stop at the first frame that does not fit (in a middle round:
+    every later array fails, nothing of it reaches the caller)."""
+    _, oc, zc, _, L = env
+    rng = np.random.default_rng(12)
+    arrs = [column("narrow", 5_000_003, 1), column("time_series", 4_194_304, 2), column("w40", 3_000_000, 3), np.zeros(0, dtype=np.int64),
+            column("constant", 6_000_000, 4), rng.choice(np.array([0, 1, 2, 7], dtype=np.uint32), 9_000_001), column("small_signed", 4_500_000, 5),
+            column("full", 2_000_000, 6), column("clustered", 5_000_000, 7), column("binary", 1, 8)]
+    want, offs = _want(oc, arrs)
+    n = len(arrs)
+    vs = [np.ascontiguousarray(a) for a in arrs]
+    descs = (L.EncodeDesc * n)()
+    for i, v in enumerate(vs):
+        descs[i].values = v.ctypes.data if v.size else None
+        descs[i].n = v.size
+        descs[i].kind = L.ELEM_U32 if v.dtype == np.uint32 else L.ELEM_I64
+    bound = sum(8 + L.lib.zbra_hip_encode_bound(v.size) for v in vs)
+    out = np.empty(bound + 64, dtype=np.uint8)
+    offsets = (C.c_uint64 * (n + 1))()
+    statuses = (C.c_int * n)()
+
+    def run(cap):
+        out[:] = 0xAB
+        for i in range(n):
+            statuses[i] = -1
+        return L.lib.zbra_hip_encode_frames(descs, n, out.ctypes.data_as(C.c_void_p), cap, offsets, statuses)
+
+    for cap in (bound, len(want), len(want) + 12345):          # rounds run ahead / wait for each other / a mix
+        assert run(cap) == 0
+        assert list(statuses) == [0] * n and list(offsets) == [int(o) for o in offs]
+        assert out[: len(want)].tobytes() == want and (out[len(want):] == 0xAB).all(), cap
+    for k in (6, 2, 0):                                       # frame k misses one byte
+        cap = int(offs[k + 1]) - 1
+        assert run(cap) == L.ERR_CAPACITY
+        assert list(statuses) == [0] * k + [L.ERR_CAPACITY] * (n - k), k
+        assert list(offsets) == [int(o) for o in offs[: k + 1]] + [int(offs[k])] * (n - k), k
+        assert out[: offs[k]].tobytes() == want[: offs[k]], k
+        assert (out[offs[k]:] == 0xAB).all(), "bytes of frames that were not laid out reached the caller"
+
+
 def test_frames_dev_misaligned_with_guards(env):
     torch, oc, _, device, L = env
     arrs = [column(k, n, 40 + i) for i, (k, n) in enumerate([("narrow", 4097), ("full", 2048), ("binary", 1), ("constant", 0),
