@@ -98,12 +98,15 @@ static uint64_t launch_limit();
 
 template <int DT, int TH>
 static void launch_decode_t(const DecodeConfig &c, hipStream_t stream, const DecodePlan *plans, const uint64_t *ts,
-                            const uint32_t *tmap, uint32_t nd, uint64_t first_tile, uint64_t all_tiles, uint32_t order) {
+                            const uint32_t *tmap, uint32_t nd, uint64_t first_tile, uint64_t all_tiles, uint32_t order, uint32_t per_array) {
     // c.xcd: 2 = the order the caller worked out (decode_tile_order); anything else forces that order (tuning)
     const uint32_t want = c.xcd == 2 ? order : (uint32_t)c.xcd;
     // tiles per launch: a multiple of 8 (whole rounds of the XCDs) within the dispatch limit
     uint64_t per = launch_limit() / TH & ~7ull;
     if (per == 0) per = 8;
+    // ceil(2^64 / per_array): the kernel's multiply-high in place of a division (per_array >= 1; for 1 the quotient is t itself)
+    const uint64_t per_inv = per_array > 1 ? ~0ull / per_array + 1 : 0;
+    if (per_array == 1 || first_tile + all_tiles > 0xFFFFFFFFull) per_array = 0;  // the table serves these
     for (uint64_t done = 0; done < all_tiles; done += per) {
         const uint64_t base = first_tile + done;
         const uint64_t ntiles = all_tiles - done < per ? all_tiles - done : per;
@@ -120,7 +123,7 @@ static void launch_decode_t(const DecodeConfig &c, hipStream_t stream, const Dec
         const dim3 g(grid), b(TH);
         const uint32_t x = ((uint64_t)grid == ntiles && ntiles >= 64) ? want : 0u;
 #define ZBRA_LAUNCH_DECODE(NTV, DIR) \
-    hipLaunchKernelGGL((decode_tiles_kernel<DT, TH, NTV, DIR>), g, b, 0, stream, plans, ts, tmap, nd, base, ntiles, x)
+    hipLaunchKernelGGL((decode_tiles_kernel<DT, TH, NTV, DIR>), g, b, 0, stream, plans, ts, tmap, nd, base, ntiles, x, per_array, per_inv)
         switch ((c.nt & 3) * 2 + (c.direct == 1 ? 1 : 0)) {
             case 0: ZBRA_LAUNCH_DECODE(0, false); break;
             case 1: ZBRA_LAUNCH_DECODE(0, true); break;
@@ -136,7 +139,7 @@ static void launch_decode_t(const DecodeConfig &c, hipStream_t stream, const Dec
 }
 
 typedef void (*DecodeLauncher)(const DecodeConfig &, hipStream_t, const DecodePlan *, const uint64_t *, const uint32_t *,
-                               uint32_t, uint64_t, uint64_t, uint32_t);
+                               uint32_t, uint64_t, uint64_t, uint32_t, uint32_t);
 struct DecodeShape { int tile, threads; DecodeLauncher fn; };
 static const DecodeShape kDecodeShapes[] = {  // the default and the alternatives it was measured against
     {2048, 512, launch_decode_t<2048, 512>}, {2048, 256, launch_decode_t<2048, 256>}, {1024, 256, launch_decode_t<1024, 256>},
@@ -234,9 +237,19 @@ static inline uint32_t decode_tile_order(uint64_t encoded_bytes, uint64_t values
 }
 
 static void launch_decode(hipStream_t stream, const DecodePlan *plans, const uint64_t *ts, const uint32_t *tmap, uint32_t nd,
-                          uint64_t ntiles, uint32_t order) {
+                          uint64_t ntiles, uint32_t order, uint32_t per_array = 0) {
     const Tuning &t = tuning();
-    t.decode_fn(t.decode, stream, plans, ts, tmap, nd, 0, ntiles, order);
+    t.decode_fn(t.decode, stream, plans, ts, tmap, nd, 0, ntiles, order, per_array);
+}
+// The tiles every array of a submission has, if they all have the same number (and more than one array); else 0.
+static uint32_t uniform_tiles(const zbra_array_desc *descs, size_t nd) {
+    static const bool off = [] { const char *e = getenv("ZBRA_HIP_DECODE_UNIFORM"); return e && atoi(e) == 0; }();  // A/B aid
+    if (nd < 2 || off) return 0;
+    const uint64_t per = decode_tiles_of(descs[0].count, descs[0].kind);
+    if (per == 0 || per > 0xFFFFFFFFull) return 0;
+    for (size_t i = 1; i < nd; i++)
+        if (decode_tiles_of(descs[i].count, descs[i].kind) != per) return 0;
+    return (uint32_t)per;
 }
 
 // Narrow submissions (every array at most Tuning::warm_bits encoded bits per value, warm_min_bytes or more
@@ -287,11 +300,11 @@ static WarmPlan warm_plan_for(const zbra_array_desc *descs, size_t nd, uint64_t 
 // Tile kernel launches of one submission: all its tiles at once, or chunk by chunk behind the
 // warm-up of each chunk.
 static void launch_decode_submission(hipStream_t stream, const DecodePlan *plans, const uint64_t *ts, const uint32_t *tmap, uint32_t nd,
-                                     uint64_t first, uint64_t ntiles, uint32_t order, const WarmPlan &wp) {
+                                     uint64_t first, uint64_t ntiles, uint32_t order, const WarmPlan &wp, uint32_t per_array = 0) {
     const Tuning &t = tuning();
     DecodeConfig c = t.decode;
     if (!wp.on) {
-        t.decode_fn(c, stream, plans, ts, tmap, nd, first, ntiles, order);
+        t.decode_fn(c, stream, plans, ts, tmap, nd, first, ntiles, order, per_array);
         return;
     }
     c.nt = 2;      // plain loads (they hit what the warm-up left), nontemporal stores
@@ -301,7 +314,7 @@ static void launch_decode_submission(hipStream_t stream, const DecodePlan *plans
         const unsigned grid = (unsigned)((n + wp.tiles_per_wg - 1) / wp.tiles_per_wg);
         hipLaunchKernelGGL((warm_tiles_kernel<2048>), dim3(grid), dim3(256), 0, stream, plans, ts, tmap, nd, first + done, n, wp.tiles_per_wg,
                            t.warm_bits > 31 ? 31u : t.warm_bits);
-        t.decode_fn(c, stream, plans, ts, tmap, nd, first + done, n, order);
+        t.decode_fn(c, stream, plans, ts, tmap, nd, first + done, n, order, per_array);
     }
 }
 
@@ -422,7 +435,7 @@ static int decode_batch_dev(DeviceCtx *ctx, const zbra_array_desc *descs, size_t
                            d_plans, d_map, d_results, d_orig);
         if (ntiles && !mixed) {
             launch_decode_submission(stream, d_plans, d_ts, d_map, (uint32_t)nd, 0, ntiles, decode_tile_order(all_bytes, all_values, nd),
-                                     all_narrow ? warm_plan_of(ntiles, all_bytes) : WarmPlan());
+                                     all_narrow ? warm_plan_of(ntiles, all_bytes) : WarmPlan(), uniform_tiles(descs, nd));
         } else if (ntiles) {
             launch_decode_submission(stream, d_plans, d_ts, d_map, (uint32_t)nd, 0, n_tiles, decode_tile_order(n_bytes, n_values, n_narrow),
                                      warm_plan_of(n_tiles, n_bytes));
@@ -683,7 +696,7 @@ static int decode_batch_dev_noalloc(DeviceCtx *ctx, const zbra_array_desc *descs
         hipLaunchKernelGGL(plan_decode_noalloc_kernel, dim3(n), dim3(256), 0, stream, c, (uint32_t)first, n, sc->plans, sc->tile_start,
                            sc->tile_map, d_results);
     }
-    if (ntiles) launch_decode(stream, sc->plans, sc->tile_start, sc->tile_map, (uint32_t)nd, ntiles, decode_tile_order(all_bytes, all_values, nd));
+    if (ntiles) launch_decode(stream, sc->plans, sc->tile_start, sc->tile_map, (uint32_t)nd, ntiles, decode_tile_order(all_bytes, all_values, nd), uniform_tiles(descs, nd));
     return hip_status(hipGetLastError());
 }
 
@@ -881,8 +894,16 @@ static int encode_batch_dev(DeviceCtx *ctx, const EncodeItem *items, size_t nd, 
                 const unsigned gp = grid_for(ntiles, (uint64_t)pack_grid_cap() < pack_most ? pack_grid_cap() : (unsigned)pack_most);
                 static const int pack_xcd_env = [] { const char *e = getenv("ZBRA_HIP_PACK_XCD"); return e ? atoi(e) : -1; }();
                 const bool pack_xcd = pack_xcd_env >= 0 ? pack_xcd_env != 0 : nd > 1;
+                // every array with the same number of tiles (Blocks of equal row counts): no tile -> array table read
+                uint32_t per_array = 0;
+                if (nd > 1 && ntiles <= 0xFFFFFFFFull) {
+                    const uint64_t per = tiles_of(items[0].n);
+                    bool same = per > 1 && per <= 0xFFFFFFFFull;
+                    for (size_t i = 1; same && i < nd; i++) same = tiles_of(items[i].n) == per;
+                    if (same) per_array = (uint32_t)per;
+                }
                 hipLaunchKernelGGL(enc_pack_kernel, dim3(gp), dim3(THREADS), 0, stream, d_jobs, d_ts, d_map, (uint32_t)nd, ntiles,
-                                   (pack_xcd && (uint64_t)gp == ntiles && ntiles >= 64) ? 1u : 0u);
+                                   (pack_xcd && (uint64_t)gp == ntiles && ntiles >= 64) ? 1u : 0u, per_array, per_array ? ~0ull / per_array + 1 : 0ull);
             }
         } else {
             hipLaunchKernelGGL(enc_report_median_kernel, dim3(ga), dim3(256), 0, stream, d_jobs, (uint32_t)nd, d_results);
