@@ -127,9 +127,14 @@ enum SelectMode : uint32_t {
 };
 
 constexpr uint32_t MICRO_KEYS = 8;     // brackets of fewer keys than this are counted in per-lane columns (see SEL_BRACKET_MICRO)
-constexpr int SAMPLE = 4096;          // sample keys of an array (four per lane of the sampling workgroup)
+#ifndef ZBRA_SAMPLE  // tuning builds: -DZBRA_SAMPLE=16384 -DZBRA_SAMPLE_MARGIN=256 -DZBRA_SAMPLE_WAVES=4
+#define ZBRA_SAMPLE 4096
+#define ZBRA_SAMPLE_MARGIN 128
+#define ZBRA_SAMPLE_WAVES 8
+#endif
+constexpr int SAMPLE = ZBRA_SAMPLE;   // sample keys of an array (four per lane of the sampling workgroup)
 constexpr int SAMPLE_THREADS = 1024;  // lanes of the sampling workgroup
-constexpr int SAMPLE_MARGIN = 128;    // sample ranks either side: 4 sigma, sigma = sqrt(SAMPLE)/2 = 32
+constexpr int SAMPLE_MARGIN = ZBRA_SAMPLE_MARGIN;  // sample ranks either side: 4 sigma, sigma = sqrt(SAMPLE)/2 = 32
 constexpr int CAND_DIV = 4;           // candidate list capacity = n / CAND_DIV (a bracket holds ~6 % of n)
 #ifndef ZBRA_CAND_LDS
 #define ZBRA_CAND_LDS 2048
@@ -375,7 +380,7 @@ __device__ __forceinline__ void select_two_ranks(const uint64_t (&key)[SAMPLE_PE
 
 // One workgroup per array.  Held at 64 VGPRs (it wants 72 and spills 4) so that two workgroups of 1024
 // lanes fit a CU: three thousand 2^14-row arrays 121 -> 98 us, a single array the same 14 us.
-__global__ __launch_bounds__(SAMPLE_THREADS, 8) void enc_sample_kernel(EncodeJob *__restrict__ jobs, uint32_t nd, uint32_t use_bracket) {
+__global__ __launch_bounds__(SAMPLE_THREADS, ZBRA_SAMPLE_WAVES) void enc_sample_kernel(EncodeJob *__restrict__ jobs, uint32_t nd, uint32_t use_bracket) {
     __shared__ SampleShared sh;
     const uint32_t a = blockIdx.x;
     if (a >= nd) return;
