@@ -1549,9 +1549,8 @@ __device__ __forceinline__ void stage_zigzag(const EncodeJob &job, uint64_t v0, 
 // busy (16-B chunks would leave most of them idle while the rest walk 32 / w values per dword,
 // four dwords each): the u32 tag column of the sum-typed table packs in 0.30 ms instead of 0.49.
 constexpr uint32_t NARROW_W = 8;
-__device__ __forceinline__ void pack_tile_narrow(const EncodeJob &job, uint64_t v0, uint32_t nv, uint32_t *zz) {
+__device__ __forceinline__ void pack_tile_narrow(const EncodeJob &job, uint32_t w, uint64_t v0, uint32_t nv, uint32_t *zz) {
     const uint32_t tid = threadIdx.x;
-    const uint32_t w = job.width;
     stage_zigzag(job, v0, nv, zz);
     const uintptr_t G = (uintptr_t)job.out + 13 + ((v0 * w) >> 3);
     const uint32_t nbytes = (nv * w + 7u) >> 3;
@@ -1602,9 +1601,8 @@ __device__ __forceinline__ void pack_tile_narrow(const EncodeJob &job, uint64_t 
     __syncthreads();
 }
 
-__device__ __forceinline__ void pack_tile_packed(const EncodeJob &job, uint64_t v0, uint32_t nv, uint32_t *zz) {
+__device__ __forceinline__ void pack_tile_packed(const EncodeJob &job, uint32_t w, uint64_t v0, uint32_t nv, uint32_t *zz) {
     const uint32_t tid = threadIdx.x;
-    const uint32_t w = job.width;
     stage_zigzag(job, v0, nv, zz);
     const uintptr_t G = (uintptr_t)job.out + 13 + ((v0 * w) >> 3);
     const uint32_t nbytes = (nv * w + 7u) >> 3;
@@ -1711,23 +1709,50 @@ __global__ void enc_report_median_kernel(const EncodeJob *__restrict__ jobs, uin
 // per_array / per_array_inv: as in the decode tile kernel: when every array of the submission has
 // the same number of tiles, tile t belongs to array t / per_array (a multiply-high by
 // ceil(2^64 / per_array), exact below 2^32 tiles) and the table is not read.
+// FINALIZE (a single array with values, not framed): no enc_finalize_kernel ran before this launch.
+// Every workgroup derives the width and the capacity check itself (a few scalar operations on the
+// job it loads anyway), and the workgroup of tile 0 writes the 13 header bytes and the result words:
+// one dependent launch less per encode.
+template <bool FINALIZE>
 __global__ __launch_bounds__(THREADS) void enc_pack_kernel(const EncodeJob *__restrict__ jobs,
                                                             const uint64_t *__restrict__ tile_start,
                                                             const uint32_t *__restrict__ tile_map, uint32_t nd,
-                                                            uint64_t ntiles, uint32_t xcd_chunked, uint32_t per_array, uint64_t per_array_inv) {
+                                                            uint64_t ntiles, uint32_t xcd_chunked, uint32_t per_array, uint64_t per_array_inv,
+                                                            zbra_dev_result *results) {
     __shared__ __attribute__((aligned(16))) uint64_t zz64[TILE];  // 64-bit zig-zag values of a raw tile; the packed paths use half of it
     uint32_t *zz = (uint32_t *)zz64;
     // xcd_chunked implies gridDim.x == ntiles: exactly one trip through the loop
     uint64_t t = xcd_chunked ? xcd_chunked_tile(blockIdx.x, ntiles) : blockIdx.x;
     for (; t < ntiles; t += gridDim.x) {
-        const uint32_t a = per_array ? (uint32_t)(((unsigned __int128)(uint32_t)t * per_array_inv) >> 64) : nd > 1 ? tile_map[t] : 0;
+        const uint32_t a = FINALIZE ? 0u : per_array ? (uint32_t)(((unsigned __int128)(uint32_t)t * per_array_inv) >> 64) : nd > 1 ? tile_map[t] : 0;
         const EncodeJob &job = jobs[a];
-        if (job.width == WIDTH_SKIP) continue;
+        uint32_t w = job.width;
+        if (FINALIZE) {  // what enc_finalize_kernel does for an array with values
+            if (job.need_or) w = width_of(job.or_bits);
+            const uint64_t packed_len = 1 + (w >= 32 ? job.n * 8 : (job.n * w + 7) / 8);
+            const bool fits = job.cap >= 12 + packed_len;
+            if (t == 0 && threadIdx.x == 0) {
+                zbra_dev_result r;
+                r.status = fits ? ZBRA_OK : ZBRA_ERR_CAPACITY; r.width = w; r.out_count = fits ? 12 + packed_len : 0;
+                r.midpoint = job.midpoint; r.packed_len = packed_len;
+                if (results) results[0] = r;
+                if (fits) {
+                    const uint64_t m = (uint64_t)job.midpoint;
+                    for (int b = 0; b < 8; b++) job.out[b] = (uint8_t)(m >> (8 * b));
+                    const uint32_t pl = (uint32_t)packed_len;  // `as u32`, compression.rs:288
+                    for (int b = 0; b < 4; b++) job.out[8 + b] = (uint8_t)(pl >> (8 * b));
+                    job.out[12] = (uint8_t)w;
+                }
+            }
+            if (!fits) return;
+        } else if (w == WIDTH_SKIP) {
+            continue;
+        }
         const uint64_t v0 = (per_array ? t - (uint64_t)a * per_array : t - tile_start[a]) * TILE;
         const uint64_t left = job.n - v0;
         const uint32_t nv = left < (uint64_t)TILE ? (uint32_t)left : (uint32_t)TILE;
-        if (job.width - (NARROW_W + 1) < 31u - NARROW_W) pack_tile_packed(job, v0, nv, zz);  // NARROW_W < w < 32
-        else if (job.width <= NARROW_W) pack_tile_narrow(job, v0, nv, zz);
+        if (w - (NARROW_W + 1) < 31u - NARROW_W) pack_tile_packed(job, w, v0, nv, zz);  // NARROW_W < w < 32
+        else if (w <= NARROW_W) pack_tile_narrow(job, w, v0, nv, zz);
         else pack_tile_raw(job, v0, nv, zz64);
     }
 }
