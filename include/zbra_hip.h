@@ -24,7 +24,10 @@
  *     device (status, lengths) land in a zbra_dev_result in device memory;
  *   - all entry points use the calling thread's current HIP device; calls on
  *     different streams or devices may run concurrently from different
- *     threads.  There is no CPU fallback: without a usable device every
+ *     threads.  Host-pointer calls from several threads on ONE device run
+ *     two at a time (each on its own streams, pinned buffers and device
+ *     buffers; ZBRA_HIP_HOST_LANES=1..4 changes the number) and queue
+ *     beyond that.  There is no CPU fallback: without a usable device every
  *     compute entry point fails with ZBRA_ERR_NO_DEVICE.
  */
 #ifndef ZBRA_HIP_H

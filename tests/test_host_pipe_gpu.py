@@ -92,7 +92,8 @@ def test_piecewise_decode_u32(env):
 
 
 def test_host_calls_from_threads(env):
-    """Host-pointer calls are serialised per device; concurrent callers must all get their own bytes."""
+    """Host-pointer calls of one device run on a few lanes at a time (each with its own streams, rings
+    and device buffers) and queue beyond that; concurrent callers must all get their own bytes."""
     oc, zc = env
     n = (1 << 20) + 17
     cols = [_narrow(n, 100 + t) + t * 1_000_003 for t in range(4)]
@@ -109,6 +110,70 @@ def test_host_calls_from_threads(env):
             errs.append((t, ex))
 
     ts = [threading.Thread(target=work, args=(t,)) for t in range(4)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert not errs, errs
+
+
+def test_every_host_entry_point_from_more_threads_than_lanes(env):
+    """Six threads, each a different mix of host-pointer calls (single arrays of several sizes incl.
+    a piecewise decode, stage functions, framed batches both ways), all at once: more callers than
+    the device has host lanes, so lanes are shared in turn and every call must still see only its
+    own buffers.  Everything against the oracle."""
+    oc, zc = env
+    rng = np.random.default_rng(77)
+    big_n = 2 * PIECE + 1234                       # piecewise decode: two streams and four events of a lane
+    big = _narrow(big_n, 9)
+    big_e = oc.compress_int_array(big)
+    mids = [_narrow((1 << 18) + 13 * t, 200 + t) - t * 999 for t in range(6)]
+    wides = [rng.integers(-(1 << 62), 1 << 62, (1 << 16) + t, dtype=np.int64) for t in range(6)]
+    tags = [rng.choice(np.array([0, 1, 2, 7], dtype=np.uint32), (1 << 19) + t) for t in range(6)]
+    batch = [_narrow(5000 + 777 * k, 300 + k) for k in range(40)] + [np.zeros(0, dtype=np.int64), wides[0][:3001]]
+    batch_frames = b"".join(struct.pack("<II", v.size, len(e)) + e for v, e in ((v, oc.compress_int_array(v)) for v in batch))
+    errs = []
+
+    def single(t):
+        for _ in range(3):
+            e = zc.compress_int_array(mids[t]); assert e == oc.compress_int_array(mids[t])
+            assert np.array_equal(zc.decompress_int_array(e, mids[t].size), mids[t])
+            e = zc.compress_int_array(wides[t]); assert e == oc.compress_int_array(wides[t])
+            assert np.array_equal(zc.decompress_int_array(e, wides[t].size), wides[t])
+            e = zc.compress_u32_array(tags[t]); assert e == oc.compress_int_array(tags[t].astype(np.int64))
+            assert np.array_equal(zc.decompress_u32_array(e, tags[t].size), tags[t])
+
+    def piecewise(t):
+        for _ in range(2):
+            assert np.array_equal(zc.decompress_int_array(big_e, big_n), big)
+
+    def stages(t):
+        for _ in range(3):
+            mid, deltas = zc.frame_of_reference_encode(mids[t])
+            omid, odeltas = oc.frame_of_reference_encode(mids[t])
+            assert mid == omid and np.array_equal(deltas, odeltas)
+            zz = zc.zig_zag_encode(deltas); assert np.array_equal(zz, oc.zig_zag_encode(odeltas))
+            packed = zc.bp64_pack(zz); assert packed == oc.bp64_pack(zz)
+            assert np.array_equal(zc.bp64_unpack(packed, zz.size), zz)
+            assert np.array_equal(zc.frame_of_reference_decode(mid, zc.zig_zag_decode(zz)), mids[t])
+
+    def framed(t):
+        for _ in range(3):
+            frames, offs = zc.write_int_arrays_compressed(batch)
+            assert frames == batch_frames
+            got = zc.read_int_arrays_compressed([(frames[offs[k] + 8:offs[k + 1]], batch[k].size, np.int64) for k in range(len(batch))])
+            for g, v in zip(got, batch):
+                assert np.array_equal(g, v)
+
+    jobs = [single, piecewise, stages, framed, single, framed]
+
+    def work(t):
+        try:
+            jobs[t](t)
+        except Exception as ex:  # noqa: BLE001
+            errs.append((t, jobs[t].__name__, repr(ex)))
+
+    ts = [threading.Thread(target=work, args=(t,)) for t in range(len(jobs))]
     for t in ts:
         t.start()
     for t in ts:

@@ -54,13 +54,13 @@ int current_ctx(DeviceCtx **out) {
     if (it != g_ctx.end()) { *out = it->second; return ZBRA_OK; }
     DeviceCtx *c = new DeviceCtx();
     c->device = dev;
-    e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    e = hipStreamCreateWithFlags(&c->host_lanes[0].stream, hipStreamNonBlocking);
     if (e != hipSuccess) { delete c; return hip_status(e); }
     // this device's copy of `scratch` (device `dev` is current: hipGetDevice just said so)
     void *sp = nullptr;
     e = hipGetSymbolAddress(&sp, HIP_SYMBOL(scratch));
     if (e != hipSuccess || !sp) {
-        (void)hipStreamDestroy(c->stream);
+        (void)hipStreamDestroy(c->host_lanes[0].stream);
         delete c;
         return e != hipSuccess ? hip_status(e) : ZBRA_ERR_NO_DEVICE;
     }
@@ -947,7 +947,7 @@ static int host_check_decode(const uint8_t *data, size_t len, size_t count, size
 // two directions of the link work at the same time.
 constexpr size_t HOST_PIECE_BYTES = (size_t)64 << 20;
 
-static int decode_host_pieces(DeviceCtx *ctx, const uint8_t *data, size_t used, size_t count, void *out, uint32_t kind) {
+static int decode_host_pieces(DeviceCtx *ctx, HostLane *hl, const uint8_t *data, size_t used, size_t count, void *out, uint32_t kind) {
     const size_t esz = kind == ZBRA_ELEM_I64 ? 8 : 4;
     const size_t per = HOST_PIECE_BYTES / esz;  // values per piece: a multiple of every tile size
     const size_t np = (count + per - 1) / per;
@@ -969,8 +969,8 @@ static int decode_host_pieces(DeviceCtx *ctx, const uint8_t *data, size_t used, 
         const uint64_t o = w == 0 ? 0 : w < 32 ? (v1 * w + 7) / 8 : v1 * 8;
         return (size_t)(13 + (o < avail ? o : avail));
     };
-    if (!ctx->stream2) ZBRA_HIP_TRY(hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking));
-    for (hipEvent_t &e : ctx->piece_done)
+    if (!hl->stream2) ZBRA_HIP_TRY(hipStreamCreateWithFlags(&hl->stream2, hipStreamNonBlocking));
+    for (hipEvent_t &e : hl->piece_done)
         if (!e) ZBRA_HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     // plans: 128 B per piece = DecodePlan at +0, tile_start {0, ntiles} at +64
     Slot *s;
@@ -983,35 +983,35 @@ static int decode_host_pieces(DeviceCtx *ctx, const uint8_t *data, size_t used, 
         // stays at the last byte that was uploaded (dev_in holds used + 16 bytes, no more), so the
         // aligned 16-byte chunk a lane may touch before it zeroes the value lies inside dev_in.
         const uint64_t oc = o < avail ? o : avail;
-        p.payload = (const uint8_t *)ctx->dev_in.ptr + 13 + oc;
-        p.out = (char *)ctx->dev_out.ptr + v0 * esz;
+        p.payload = (const uint8_t *)hl->dev_in.ptr + 13 + oc;
+        p.out = (char *)hl->dev_out.ptr + v0 * esz;
         p.count = nv; p.midpoint = mid; p.avail = avail - oc; p.width = w; p.kind = kind;
         std::memcpy((char *)s->host + c * 128, &p, sizeof(p));
         const uint64_t ts[2] = {0, decode_tiles_of(nv, kind)};
         std::memcpy((char *)s->host + c * 128 + 64, ts, sizeof(ts));
     }
-    hipStream_t up = ctx->stream, down = ctx->stream2;
+    hipStream_t up = hl->stream, down = hl->stream2;
     size_t submitted = 0;  // pieces uploaded and launched so far
     auto submit = [&]() -> int {
         const size_t c = submitted;
         const size_t b0 = first_byte(c), b1 = end_byte(c);
-        if (b1 > b0) ZBRA_TRY(ctx->pipe_up.to_device((char *)ctx->dev_in.ptr + b0, data + b0, b1 - b0, up));
+        if (b1 > b0) ZBRA_TRY(hl->pipe_up.to_device((char *)hl->dev_in.ptr + b0, data + b0, b1 - b0, up));
         const uint64_t v0 = (uint64_t)c * per, nv = count - v0 < per ? count - v0 : per;
         launch_decode(up, (const DecodePlan *)((char *)s->dev + c * 128), (const uint64_t *)((char *)s->dev + c * 128 + 64), nullptr, 1u,
                       decode_tiles_of(nv, kind), w >= 32 ? 0u : w >= 16 ? 16u : w >= 10 ? 1u : 0u);
         ZBRA_HIP_TRY(hipGetLastError());
-        ZBRA_HIP_TRY(hipEventRecord(ctx->piece_done[c % 4], up));
+        ZBRA_HIP_TRY(hipEventRecord(hl->piece_done[c % 4], up));
         submitted++;
         return ZBRA_OK;
     };
     int st = hip_status(hipMemcpyAsync(s->dev, s->host, np * 128, hipMemcpyHostToDevice, up));
     size_t waited = 0;  // pieces the way back has been told to wait for
     if (st == ZBRA_OK)
-        st = ctx->pipe.to_host(out, ctx->dev_out.ptr, count * esz, down, [&](size_t last_byte) -> int {
+        st = hl->pipe.to_host(out, hl->dev_out.ptr, count * esz, down, [&](size_t last_byte) -> int {
             // the chunk ending at last_byte needs pieces up to this one; keep one more in flight
             const size_t need = (last_byte + HOST_PIECE_BYTES - 1) / HOST_PIECE_BYTES;
             while (submitted < np && submitted < need + 1) ZBRA_TRY(submit());
-            for (; waited < need; waited++) ZBRA_HIP_TRY(hipStreamWaitEvent(down, ctx->piece_done[waited % 4], 0));
+            for (; waited < need; waited++) ZBRA_HIP_TRY(hipStreamWaitEvent(down, hl->piece_done[waited % 4], 0));
             return ZBRA_OK;
         });
     // nothing of this call may still run when the arenas are handed to the next one
@@ -1030,19 +1030,21 @@ static int decode_host(const uint8_t *data, size_t len, size_t count, void *out,
     if (!out) return ZBRA_ERR_INVALID_ARG;
     DeviceCtx *ctx;
     ZBRA_TRY(current_ctx(&ctx));
-    std::lock_guard<std::mutex> g(ctx->host_mu);
+    HostLaneLock lane_lock(ctx);
+    HostLane *hl = lane_lock.lane;
+    ZBRA_TRY(hl->ensure_stream());
     const size_t esz = kind == ZBRA_ELEM_I64 ? 8 : 4;
     uint32_t packed_len;
     std::memcpy(&packed_len, data + 8, 4);               // E sits at any byte address
     const size_t used = 12 + (size_t)packed_len;         // bytes after 12 + packed_len are ignored
-    ZBRA_TRY(DeviceCtx::grow_dev(ctx->dev_in, used + 16));
-    ZBRA_TRY(DeviceCtx::grow_dev(ctx->dev_out, count * esz));
-    if (count * esz >= 2 * HOST_PIECE_BYTES && HostPipe::enabled()) return decode_host_pieces(ctx, data, used, count, out, kind);
-    ZBRA_TRY(ctx->pipe.to_device(ctx->dev_in.ptr, data, used, ctx->stream));
+    ZBRA_TRY(DeviceCtx::grow_dev(hl->dev_in, used + 16));
+    ZBRA_TRY(DeviceCtx::grow_dev(hl->dev_out, count * esz));
+    if (count * esz >= 2 * HOST_PIECE_BYTES && HostPipe::enabled()) return decode_host_pieces(ctx, hl, data, used, count, out, kind);
+    ZBRA_TRY(hl->pipe.to_device(hl->dev_in.ptr, data, used, hl->stream));
     zbra_array_desc d;
-    d.data = (const uint8_t *)ctx->dev_in.ptr; d.len = used; d.count = count; d.out = ctx->dev_out.ptr; d.kind = kind; d.reserved = 0;
-    ZBRA_TRY(decode_batch_dev(ctx, &d, 1, nullptr, ctx->stream));
-    ZBRA_TRY(ctx->pipe.to_host(out, ctx->dev_out.ptr, count * esz, ctx->stream));
+    d.data = (const uint8_t *)hl->dev_in.ptr; d.len = used; d.count = count; d.out = hl->dev_out.ptr; d.kind = kind; d.reserved = 0;
+    ZBRA_TRY(decode_batch_dev(ctx, &d, 1, nullptr, hl->stream));
+    ZBRA_TRY(hl->pipe.to_host(out, hl->dev_out.ptr, count * esz, hl->stream));
     return ZBRA_OK;
 }
 
@@ -1053,21 +1055,23 @@ static int encode_host(const void *values, size_t n, uint32_t kind, uint8_t *out
     if (n > MAX_COUNT) return ZBRA_ERR_INVALID_ARG;
     DeviceCtx *ctx;
     ZBRA_TRY(current_ctx(&ctx));
-    std::lock_guard<std::mutex> g(ctx->host_mu);
+    HostLaneLock lane_lock(ctx);
+    HostLane *hl = lane_lock.lane;
+    ZBRA_TRY(hl->ensure_stream());
     const size_t esz = kind == ZBRA_ELEM_I64 ? 8 : 4;
     const size_t bound = zbra_hip_encode_bound(n);
-    ZBRA_TRY(DeviceCtx::grow_dev(ctx->dev_in, n * esz));
-    ZBRA_TRY(DeviceCtx::grow_dev(ctx->dev_out, bound + 16));
-    ZBRA_TRY(DeviceCtx::grow_dev(ctx->dev_tmp, sizeof(zbra_dev_result)));
-    ZBRA_TRY(ctx->pipe.to_device(ctx->dev_in.ptr, values, n * esz, ctx->stream));
-    EncodeItem it{ctx->dev_in.ptr, n, kind, (uint8_t *)ctx->dev_out.ptr, bound};
-    ZBRA_TRY(encode_batch_dev(ctx, &it, 1, (zbra_dev_result *)ctx->dev_tmp.ptr, ctx->stream));
+    ZBRA_TRY(DeviceCtx::grow_dev(hl->dev_in, n * esz));
+    ZBRA_TRY(DeviceCtx::grow_dev(hl->dev_out, bound + 16));
+    ZBRA_TRY(DeviceCtx::grow_dev(hl->dev_tmp, sizeof(zbra_dev_result)));
+    ZBRA_TRY(hl->pipe.to_device(hl->dev_in.ptr, values, n * esz, hl->stream));
+    EncodeItem it{hl->dev_in.ptr, n, kind, (uint8_t *)hl->dev_out.ptr, bound};
+    ZBRA_TRY(encode_batch_dev(ctx, &it, 1, (zbra_dev_result *)hl->dev_tmp.ptr, hl->stream));
     zbra_dev_result r;
-    ZBRA_HIP_TRY(hipMemcpyAsync(&r, ctx->dev_tmp.ptr, sizeof(r), hipMemcpyDeviceToHost, ctx->stream));
-    ZBRA_HIP_TRY(hipStreamSynchronize(ctx->stream));
+    ZBRA_HIP_TRY(hipMemcpyAsync(&r, hl->dev_tmp.ptr, sizeof(r), hipMemcpyDeviceToHost, hl->stream));
+    ZBRA_HIP_TRY(hipStreamSynchronize(hl->stream));
     if (r.status != ZBRA_OK) return (int)r.status;
     if (r.out_count > cap || !out) return ZBRA_ERR_CAPACITY;
-    ZBRA_TRY(ctx->pipe.to_host(out, ctx->dev_out.ptr, r.out_count, ctx->stream));
+    ZBRA_TRY(hl->pipe.to_host(out, hl->dev_out.ptr, r.out_count, hl->stream));
     *out_len = r.out_count;
     return ZBRA_OK;
 }
@@ -1079,13 +1083,15 @@ static int stage_host(const void *in, size_t in_bytes, void *out, size_t out_byt
     if (in_bytes == 0) return ZBRA_OK;
     DeviceCtx *ctx;
     ZBRA_TRY(current_ctx(&ctx));
-    std::lock_guard<std::mutex> g(ctx->host_mu);
-    ZBRA_TRY(DeviceCtx::grow_dev(ctx->dev_in, in_bytes));
-    ZBRA_TRY(DeviceCtx::grow_dev(ctx->dev_out, out_bytes));
-    ZBRA_TRY(ctx->pipe.to_device(ctx->dev_in.ptr, in, in_bytes, ctx->stream));
-    launch(ctx->dev_in.ptr, ctx->dev_out.ptr, ctx->stream);
+    HostLaneLock lane_lock(ctx);
+    HostLane *hl = lane_lock.lane;
+    ZBRA_TRY(hl->ensure_stream());
+    ZBRA_TRY(DeviceCtx::grow_dev(hl->dev_in, in_bytes));
+    ZBRA_TRY(DeviceCtx::grow_dev(hl->dev_out, out_bytes));
+    ZBRA_TRY(hl->pipe.to_device(hl->dev_in.ptr, in, in_bytes, hl->stream));
+    launch(hl->dev_in.ptr, hl->dev_out.ptr, hl->stream);
     ZBRA_HIP_TRY(hipGetLastError());
-    ZBRA_TRY(ctx->pipe.to_host(out, ctx->dev_out.ptr, out_bytes, ctx->stream));
+    ZBRA_TRY(hl->pipe.to_host(out, hl->dev_out.ptr, out_bytes, hl->stream));
     return ZBRA_OK;
 }
 
@@ -1104,17 +1110,19 @@ static int decode_host_batch(const zbra_array_desc *items, size_t n, int *status
     }
     DeviceCtx *ctx;
     ZBRA_TRY(current_ctx(&ctx));
-    std::lock_guard<std::mutex> g(ctx->host_mu);
-    ZBRA_TRY(ctx->ensure_file_lanes());
-    if (!ctx->stream2) ZBRA_HIP_TRY(hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking));
-    for (hipEvent_t &e : ctx->piece_done)
+    HostLaneLock lane_lock(ctx);
+    HostLane *hl = lane_lock.lane;
+    ZBRA_TRY(hl->ensure_stream());
+    ZBRA_TRY(hl->ensure_file_lanes());
+    if (!hl->stream2) ZBRA_HIP_TRY(hipStreamCreateWithFlags(&hl->stream2, hipStreamNonBlocking));
+    for (hipEvent_t &e : hl->piece_done)
         if (!e) ZBRA_HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     constexpr size_t MAX_IN = (size_t)16 << 20, MAX_OUT = (size_t)4 << 30, MAX_ARRAYS = 4096;
     struct Group { size_t first, end, in_bytes, out_off, out_end; };
     // status words come back into pinned memory: a copy into pageable memory would block the
     // host until the group's kernels have run, and the host has the copy back to keep fed
-    ZBRA_TRY(DeviceCtx::grow_pinned(ctx->pin_res, n * sizeof(zbra_dev_result)));
-    zbra_dev_result *results = (zbra_dev_result *)ctx->pin_res.ptr;
+    ZBRA_TRY(DeviceCtx::grow_pinned(hl->pin_res, n * sizeof(zbra_dev_result)));
+    zbra_dev_result *results = (zbra_dev_result *)hl->pin_res.ptr;
     std::vector<zbra_array_desc> descs;
     std::vector<HostPipe::Segment> segs, up;
     std::vector<Group> groups;
@@ -1140,7 +1148,7 @@ static int decode_host_batch(const zbra_array_desc *items, size_t n, int *status
             gr.out_end = total;
             groups.push_back(gr);
         }
-        ZBRA_TRY(DeviceCtx::grow_dev(ctx->dev_out, total + 16));
+        ZBRA_TRY(DeviceCtx::grow_dev(hl->dev_out, total + 16));
         // what goes back: exactly the values each array produces, known from its header, which the
         // host can read (nothing for empty / rejected arrays)
         segs.clear();
@@ -1152,7 +1160,7 @@ static int decode_host_batch(const zbra_array_desc *items, size_t n, int *status
         size_t submitted = 0, waited = 0;
         auto submit = [&]() -> int {  // upload + decode of the next group, on its lane
             const Group &gr = groups[submitted];
-            FileLane &lane = ctx->file_lanes[submitted & 1];
+            FileLane &lane = hl->file_lanes[submitted & 1];
             const size_t ng = gr.end - gr.first;
             if (lane.img.cap < gr.in_bytes + 16 || lane.res.cap < ng * sizeof(zbra_dev_result)) {
                 ZBRA_HIP_TRY(hipStreamSynchronize(lane.stream));  // a kernel may still read the old buffers
@@ -1166,30 +1174,30 @@ static int decode_host_batch(const zbra_array_desc *items, size_t n, int *status
                 const zbra_array_desc &it = items[gr.first + k];
                 if (it.len) up.push_back({o, const_cast<uint8_t *>(it.data), (size_t)it.len});
                 descs[k].data = (const uint8_t *)lane.img.ptr + o;
-                descs[k].len = it.len; descs[k].count = it.count; descs[k].out = (char *)ctx->dev_out.ptr + out_off[gr.first + k];
+                descs[k].len = it.len; descs[k].count = it.count; descs[k].out = (char *)hl->dev_out.ptr + out_off[gr.first + k];
                 descs[k].kind = it.kind; descs[k].reserved = 0;
                 o += padded_in(gr.first + k);
             }
-            ZBRA_TRY(ctx->pipe_up.to_device_segments(up.data(), up.size(), lane.img.ptr, gr.in_bytes, lane.stream));
+            ZBRA_TRY(hl->pipe_up.to_device_segments(up.data(), up.size(), lane.img.ptr, gr.in_bytes, lane.stream));
             ZBRA_TRY(decode_batch_dev(ctx, descs.data(), ng, (zbra_dev_result *)lane.res.ptr, lane.stream));
             ZBRA_HIP_TRY(hipMemcpyAsync(&results[gr.first], lane.res.ptr, ng * sizeof(zbra_dev_result), hipMemcpyDeviceToHost, lane.stream));
-            ZBRA_HIP_TRY(hipEventRecord(ctx->piece_done[submitted % 4], lane.stream));
+            ZBRA_HIP_TRY(hipEventRecord(hl->piece_done[submitted % 4], lane.stream));
             submitted++;
             return ZBRA_OK;
         };
-        st = ctx->pipe.to_host_segments(segs.data(), segs.size(), ctx->dev_out.ptr, total, ctx->stream2, [&](size_t last_byte) -> int {
+        st = hl->pipe.to_host_segments(segs.data(), segs.size(), hl->dev_out.ptr, total, hl->stream2, [&](size_t last_byte) -> int {
             // groups that produce bytes below last_byte must have been enqueued; keep one more in flight
             size_t need = waited;
             while (need < groups.size() && groups[need].out_off < last_byte) need++;
             while (submitted < groups.size() && submitted < need + 1) ZBRA_TRY(submit());
-            for (; waited < need; waited++) ZBRA_HIP_TRY(hipStreamWaitEvent(ctx->stream2, ctx->piece_done[waited % 4], 0));
+            for (; waited < need; waited++) ZBRA_HIP_TRY(hipStreamWaitEvent(hl->stream2, hl->piece_done[waited % 4], 0));
             return ZBRA_OK;
         });
         // groups whose arrays produce nothing are still decoded for their status words
         while (st == ZBRA_OK && submitted < groups.size()) st = submit();
-        const int st0 = hip_status(hipStreamSynchronize(ctx->file_lanes[0].stream));
-        const int st1 = hip_status(hipStreamSynchronize(ctx->file_lanes[1].stream));
-        const int st2 = hip_status(hipStreamSynchronize(ctx->stream2));
+        const int st0 = hip_status(hipStreamSynchronize(hl->file_lanes[0].stream));
+        const int st1 = hip_status(hipStreamSynchronize(hl->file_lanes[1].stream));
+        const int st2 = hip_status(hipStreamSynchronize(hl->stream2));
         if (st == ZBRA_OK) st = st0 != ZBRA_OK ? st0 : st1 != ZBRA_OK ? st1 : st2;
         r0 = r1;
     }
@@ -1288,20 +1296,22 @@ int zbra_hip_frame_of_reference_encode(const int64_t *values, size_t n, int64_t 
     if (n > MAX_COUNT) return ZBRA_ERR_INVALID_ARG;
     DeviceCtx *ctx;
     ZBRA_TRY(current_ctx(&ctx));
-    std::lock_guard<std::mutex> g(ctx->host_mu);
-    ZBRA_TRY(DeviceCtx::grow_dev(ctx->dev_in, n * 8));
-    ZBRA_TRY(DeviceCtx::grow_dev(ctx->dev_out, n * 8));
-    ZBRA_TRY(DeviceCtx::grow_dev(ctx->dev_tmp, sizeof(zbra_dev_result)));
-    ZBRA_TRY(ctx->pipe.to_device(ctx->dev_in.ptr, values, n * 8, ctx->stream));
-    EncodeItem it{ctx->dev_in.ptr, n, ZBRA_ELEM_I64, nullptr, 0};
-    ZBRA_TRY(encode_batch_dev(ctx, &it, 1, (zbra_dev_result *)ctx->dev_tmp.ptr, ctx->stream, ENCODE_MEDIAN_ONLY));
+    HostLaneLock lane_lock(ctx);
+    HostLane *hl = lane_lock.lane;
+    ZBRA_TRY(hl->ensure_stream());
+    ZBRA_TRY(DeviceCtx::grow_dev(hl->dev_in, n * 8));
+    ZBRA_TRY(DeviceCtx::grow_dev(hl->dev_out, n * 8));
+    ZBRA_TRY(DeviceCtx::grow_dev(hl->dev_tmp, sizeof(zbra_dev_result)));
+    ZBRA_TRY(hl->pipe.to_device(hl->dev_in.ptr, values, n * 8, hl->stream));
+    EncodeItem it{hl->dev_in.ptr, n, ZBRA_ELEM_I64, nullptr, 0};
+    ZBRA_TRY(encode_batch_dev(ctx, &it, 1, (zbra_dev_result *)hl->dev_tmp.ptr, hl->stream, ENCODE_MEDIAN_ONLY));
     const unsigned grid = grid_for((n + THREADS * 2 - 1) / (THREADS * 2), STREAM_GRID_CAP);
-    hipLaunchKernelGGL(for_sub_kernel, dim3(grid), dim3(THREADS), 0, ctx->stream, (const int64_t *)ctx->dev_in.ptr,
-                       (uint64_t)n, (const zbra_dev_result *)ctx->dev_tmp.ptr, (int64_t *)ctx->dev_out.ptr);
+    hipLaunchKernelGGL(for_sub_kernel, dim3(grid), dim3(THREADS), 0, hl->stream, (const int64_t *)hl->dev_in.ptr,
+                       (uint64_t)n, (const zbra_dev_result *)hl->dev_tmp.ptr, (int64_t *)hl->dev_out.ptr);
     ZBRA_HIP_TRY(hipGetLastError());
     zbra_dev_result r;
-    ZBRA_HIP_TRY(hipMemcpyAsync(&r, ctx->dev_tmp.ptr, sizeof(r), hipMemcpyDeviceToHost, ctx->stream));
-    ZBRA_TRY(ctx->pipe.to_host(deltas, ctx->dev_out.ptr, n * 8, ctx->stream));
+    ZBRA_HIP_TRY(hipMemcpyAsync(&r, hl->dev_tmp.ptr, sizeof(r), hipMemcpyDeviceToHost, hl->stream));
+    ZBRA_TRY(hl->pipe.to_host(deltas, hl->dev_out.ptr, n * 8, hl->stream));
     *midpoint = r.midpoint;
     return ZBRA_OK;
 }
@@ -1337,23 +1347,25 @@ int zbra_hip_bp64_pack(const uint64_t *values, size_t n, uint8_t *out, size_t ca
     if (n > MAX_COUNT) return ZBRA_ERR_INVALID_ARG;
     DeviceCtx *ctx;
     ZBRA_TRY(current_ctx(&ctx));
-    std::lock_guard<std::mutex> g(ctx->host_mu);
+    HostLaneLock lane_lock(ctx);
+    HostLane *hl = lane_lock.lane;
+    ZBRA_TRY(hl->ensure_stream());
     const size_t bound = 1 + 8 * n;
-    ZBRA_TRY(DeviceCtx::grow_dev(ctx->dev_in, n * 8));
-    ZBRA_TRY(DeviceCtx::grow_dev(ctx->dev_out, 12 + bound + 32));
-    ZBRA_TRY(DeviceCtx::grow_dev(ctx->dev_tmp, sizeof(zbra_dev_result)));
-    ZBRA_TRY(ctx->pipe.to_device(ctx->dev_in.ptr, values, n * 8, ctx->stream));
+    ZBRA_TRY(DeviceCtx::grow_dev(hl->dev_in, n * 8));
+    ZBRA_TRY(DeviceCtx::grow_dev(hl->dev_out, 12 + bound + 32));
+    ZBRA_TRY(DeviceCtx::grow_dev(hl->dev_tmp, sizeof(zbra_dev_result)));
+    ZBRA_TRY(hl->pipe.to_device(hl->dev_in.ptr, values, n * 8, hl->stream));
     // The stream is built by the encode pipeline with values taken as they are; its E layout puts
     // the width byte at +12, so `packed` is E without the 12 header bytes.
-    EncodeItem it{ctx->dev_in.ptr, n, KIND_U64_PLAIN, (uint8_t *)ctx->dev_out.ptr, 12 + bound};
-    ZBRA_TRY(encode_batch_dev(ctx, &it, 1, (zbra_dev_result *)ctx->dev_tmp.ptr, ctx->stream));
+    EncodeItem it{hl->dev_in.ptr, n, KIND_U64_PLAIN, (uint8_t *)hl->dev_out.ptr, 12 + bound};
+    ZBRA_TRY(encode_batch_dev(ctx, &it, 1, (zbra_dev_result *)hl->dev_tmp.ptr, hl->stream));
     zbra_dev_result r;
-    ZBRA_HIP_TRY(hipMemcpyAsync(&r, ctx->dev_tmp.ptr, sizeof(r), hipMemcpyDeviceToHost, ctx->stream));
-    ZBRA_HIP_TRY(hipStreamSynchronize(ctx->stream));
+    ZBRA_HIP_TRY(hipMemcpyAsync(&r, hl->dev_tmp.ptr, sizeof(r), hipMemcpyDeviceToHost, hl->stream));
+    ZBRA_HIP_TRY(hipStreamSynchronize(hl->stream));
     if (r.status != ZBRA_OK) return (int)r.status;
     const size_t len = (size_t)r.packed_len;
     if (len > cap || !out) return ZBRA_ERR_CAPACITY;
-    ZBRA_TRY(ctx->pipe.to_host(out, (uint8_t *)ctx->dev_out.ptr + 12, len, ctx->stream));
+    ZBRA_TRY(hl->pipe.to_host(out, (uint8_t *)hl->dev_out.ptr + 12, len, hl->stream));
     *out_len = len;
     return ZBRA_OK;
 }
@@ -1369,19 +1381,21 @@ int zbra_hip_bp64_unpack(const uint8_t *packed, size_t packed_len, size_t count,
     if (w >= 1 && w < 32 && (uint64_t)(packed_len - 1) < ((uint64_t)count * w + 7) / 8) return ZBRA_ERR_TRUNCATED;
     DeviceCtx *ctx;
     ZBRA_TRY(current_ctx(&ctx));
-    std::lock_guard<std::mutex> g(ctx->host_mu);
-    ZBRA_TRY(DeviceCtx::grow_dev(ctx->dev_in, packed_len + 32));
-    ZBRA_TRY(DeviceCtx::grow_dev(ctx->dev_out, count * 8));
-    ZBRA_TRY(ctx->pipe.to_device(ctx->dev_in.ptr, packed, packed_len, ctx->stream));
-    ZBRA_TRY(DeviceCtx::grow_dev(ctx->dev_tmp, 256));
+    HostLaneLock lane_lock(ctx);
+    HostLane *hl = lane_lock.lane;
+    ZBRA_TRY(hl->ensure_stream());
+    ZBRA_TRY(DeviceCtx::grow_dev(hl->dev_in, packed_len + 32));
+    ZBRA_TRY(DeviceCtx::grow_dev(hl->dev_out, count * 8));
+    ZBRA_TRY(hl->pipe.to_device(hl->dev_in.ptr, packed, packed_len, hl->stream));
+    ZBRA_TRY(DeviceCtx::grow_dev(hl->dev_tmp, 256));
     const uint64_t ntiles = decode_tiles_of(count, KIND_U64_PLAIN);
-    DecodePlan *plan = (DecodePlan *)ctx->dev_tmp.ptr;
-    uint64_t *tile_start = (uint64_t *)((char *)ctx->dev_tmp.ptr + 64);
-    hipLaunchKernelGGL(plan_unpack_kernel, dim3(1), dim3(64), 0, ctx->stream, (const uint8_t *)ctx->dev_in.ptr,
-                       (uint64_t)packed_len, (uint64_t)count, ctx->dev_out.ptr, ntiles, plan, tile_start);
-    launch_decode(ctx->stream, plan, tile_start, nullptr, 1u, ntiles, w >= 32 ? 0u : w >= 16 ? 16u : w >= 10 ? 1u : 0u);
+    DecodePlan *plan = (DecodePlan *)hl->dev_tmp.ptr;
+    uint64_t *tile_start = (uint64_t *)((char *)hl->dev_tmp.ptr + 64);
+    hipLaunchKernelGGL(plan_unpack_kernel, dim3(1), dim3(64), 0, hl->stream, (const uint8_t *)hl->dev_in.ptr,
+                       (uint64_t)packed_len, (uint64_t)count, hl->dev_out.ptr, ntiles, plan, tile_start);
+    launch_decode(hl->stream, plan, tile_start, nullptr, 1u, ntiles, w >= 32 ? 0u : w >= 16 ? 16u : w >= 10 ? 1u : 0u);
     ZBRA_HIP_TRY(hipGetLastError());
-    ZBRA_TRY(ctx->pipe.to_host(out, ctx->dev_out.ptr, count * 8, ctx->stream));
+    ZBRA_TRY(hl->pipe.to_host(out, hl->dev_out.ptr, count * 8, hl->stream));
     *out_count = count;
     return ZBRA_OK;
 }
@@ -1482,8 +1496,10 @@ int zbra_hip_encode_frames(const zbra_encode_desc *descs, size_t nd, uint8_t *ou
     }
     DeviceCtx *ctx;
     ZBRA_TRY(current_ctx(&ctx));
-    std::lock_guard<std::mutex> g(ctx->host_mu);
-    ZBRA_TRY(ctx->ensure_enc_lanes());
+    HostLaneLock lane_lock(ctx);
+    HostLane *hl = lane_lock.lane;
+    ZBRA_TRY(hl->ensure_stream());
+    ZBRA_TRY(hl->ensure_enc_lanes());
     // Rounds of consecutive arrays: bounded input bytes and array count per submission.  Rounds
     // alternate between two lanes (stream + device buffers).  This thread produces: it uploads a
     // round's values (pageable memory -> pinned ring -> device) and enqueues the batched encode with
@@ -1523,7 +1539,7 @@ int zbra_hip_encode_frames(const zbra_encode_desc *descs, size_t nd, uint8_t *ou
     std::vector<HostPipe::Segment> segs;
     auto produce = [&](size_t k) -> int {  // upload + encode of round k on its lane (which is free)
         Round &rd = rounds[k];
-        EncodeLane &lane = ctx->enc_lanes[k & 1];
+        EncodeLane &lane = hl->enc_lanes[k & 1];
         const size_t nr = rd.r1 - rd.r0;
         ZBRA_TRY(DeviceCtx::grow_dev(lane.in, rd.total_in + 16));
         ZBRA_TRY(DeviceCtx::grow_dev(lane.out, rd.room + 16));
@@ -1538,7 +1554,7 @@ int zbra_hip_encode_frames(const zbra_encode_desc *descs, size_t nd, uint8_t *ou
             items[i] = EncodeItem{(char *)lane.in.ptr + o, d.n, d.kind, nullptr, 0};
             o += in_bytes(rd.r0 + i);
         }
-        ZBRA_TRY(ctx->pipe_up.to_device_segments(segs.data(), segs.size(), lane.in.ptr, rd.total_in, lane.stream));
+        ZBRA_TRY(hl->pipe_up.to_device_segments(segs.data(), segs.size(), lane.in.ptr, rd.total_in, lane.stream));
         FrameTarget ft;
         ft.out = (uint8_t *)lane.out.ptr; ft.cap = rd.room; ft.offsets = (uint64_t *)lane.tmp.ptr;
         ZBRA_TRY(encode_batch_dev(ctx, items.data(), nr, (zbra_dev_result *)((char *)lane.tmp.ptr + rd.off_res), lane.stream, ENCODE_FULL, &ft));
@@ -1547,7 +1563,7 @@ int zbra_hip_encode_frames(const zbra_encode_desc *descs, size_t nd, uint8_t *ou
     };
     auto consume = [&](size_t k) -> int {  // frames of round k back to the caller, behind round k - 1's
         const Round &rd = rounds[k];
-        EncodeLane &lane = ctx->enc_lanes[k & 1];
+        EncodeLane &lane = hl->enc_lanes[k & 1];
         const size_t nr = rd.r1 - rd.r0;
         ZBRA_HIP_TRY(hipStreamSynchronize(lane.stream));
         const uint64_t *h_off = (const uint64_t *)lane.pin.ptr;
@@ -1555,7 +1571,7 @@ int zbra_hip_encode_frames(const zbra_encode_desc *descs, size_t nd, uint8_t *ou
         const size_t laid_out = (size_t)h_off[nr];
         size_t at;
         { std::lock_guard<std::mutex> l(mu); at = written; }
-        ZBRA_TRY(ctx->pipe.to_host(out + at, lane.out.ptr, laid_out, lane.stream));
+        ZBRA_TRY(hl->pipe.to_host(out + at, lane.out.ptr, laid_out, lane.stream));
         int err = ZBRA_OK;
         bool over = false;
         for (size_t i = 0; i < nr; i++) {
@@ -1638,7 +1654,7 @@ int zbra_hip_encode_frames(const zbra_encode_desc *descs, size_t nd, uint8_t *ou
     }
     if (st == ZBRA_OK) st = failure;
     // whatever happened, nothing of this call may still run on the lanes when they are reused
-    for (EncodeLane &l : ctx->enc_lanes) (void)hipStreamSynchronize(l.stream);
+    for (EncodeLane &l : hl->enc_lanes) (void)hipStreamSynchronize(l.stream);
     if (st != ZBRA_OK) return st;
     if (consumed < rounds.size()) {
         // a frame did not fit: every later array is reported as an empty range at the end

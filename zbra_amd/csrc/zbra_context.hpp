@@ -4,6 +4,8 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
+#include <cstdlib>
 #include <mutex>
 #include <vector>
 
@@ -74,31 +76,63 @@ struct StreamScratch {
     uint64_t used = 0;   // tick of the last use (guarded by DeviceCtx::mu)
 };
 
-struct DeviceCtx {
-    int device = -1;
-    FileLane file_lanes[2];
-    int ensure_file_lanes() {
-        for (FileLane &l : file_lanes)
-            if (!l.stream) ZBRA_HIP_TRY(hipStreamCreateWithFlags(&l.stream, hipStreamNonBlocking));
-        return ZBRA_OK;
-    }
-    EncodeLane enc_lanes[2];
-    int ensure_enc_lanes() {
-        for (EncodeLane &l : enc_lanes)
-            if (!l.stream) ZBRA_HIP_TRY(hipStreamCreateWithFlags(&l.stream, hipStreamNonBlocking));
-        return ZBRA_OK;
-    }
-    std::mutex mu;              // guards slots
-    std::vector<Slot *> slots;  // pointers stay valid while the vector grows
-    std::mutex host_mu;         // serialises host-pointer calls: they share the arenas and the stream
-    void *noalloc_scratch = nullptr;  // this device's address of the library's static scratch array (set once, at creation)
+// What ONE host-pointer call (host memory at both ends) works with: streams, grow-only device and
+// pinned buffers, the pinned rings.  A call holds the lane's mutex from start to end, so nothing of
+// one call is still in flight on the lane when the next call takes it.  A device has a few lanes, so
+// that calls from several threads overlap (one thread's upload with another's way back, or the
+// fixed latencies of many small calls); a single-threaded caller only ever uses lane 0, and the
+// other lanes hold no memory until a second thread arrives.
+struct HostLane {
+    std::mutex mu;
     hipStream_t stream = nullptr;
     hipStream_t stream2 = nullptr;            // the way back of a piecewise host decode
     hipEvent_t piece_done[4] = {nullptr, nullptr, nullptr, nullptr};
     Arena dev_in, dev_out, dev_tmp;
     Arena pin_res;              // pinned: status words of a whole-file decode
-    HostPipe pipe;              // pageable host memory <-> device, under host_mu
+    HostPipe pipe;              // pageable host memory <-> device
     HostPipe pipe_up;           // uploads issued while `pipe` is busy with the way back (piecewise decode)
+    FileLane file_lanes[2];
+    EncodeLane enc_lanes[2];
+    int ensure_stream() {
+        if (!stream) ZBRA_HIP_TRY(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+        return ZBRA_OK;
+    }
+    int ensure_file_lanes() {
+        for (FileLane &l : file_lanes)
+            if (!l.stream) ZBRA_HIP_TRY(hipStreamCreateWithFlags(&l.stream, hipStreamNonBlocking));
+        return ZBRA_OK;
+    }
+    int ensure_enc_lanes() {
+        for (EncodeLane &l : enc_lanes)
+            if (!l.stream) ZBRA_HIP_TRY(hipStreamCreateWithFlags(&l.stream, hipStreamNonBlocking));
+        return ZBRA_OK;
+    }
+};
+
+struct DeviceCtx {
+    int device = -1;
+    static constexpr int MAX_HOST_LANES = 4;
+    HostLane host_lanes[MAX_HOST_LANES];
+    // ZBRA_HIP_HOST_LANES=1..4: host-pointer calls that may run at the same time on one device
+    // (default 2: each lane that is really used holds its own pinned rings and device buffers)
+    const int n_host_lanes = [] {
+        const char *e = std::getenv("ZBRA_HIP_HOST_LANES");
+        const int v = e ? std::atoi(e) : 2;
+        return v < 1 ? 1 : v > MAX_HOST_LANES ? MAX_HOST_LANES : v;
+    }();
+    std::atomic<unsigned> host_ticket{0};
+    // The first lane nobody holds, lowest index first; with all of them taken the caller queues on
+    // one of them in turn.  Returned with its mutex HELD.
+    HostLane *lock_host_lane() {
+        for (int i = 0; i < n_host_lanes; i++)
+            if (host_lanes[i].mu.try_lock()) return &host_lanes[i];
+        HostLane *l = &host_lanes[host_ticket.fetch_add(1) % (unsigned)n_host_lanes];
+        l->mu.lock();
+        return l;
+    }
+    std::mutex mu;              // guards slots
+    std::vector<Slot *> slots;  // pointers stay valid while the vector grows
+    void *noalloc_scratch = nullptr;  // this device's address of the library's static scratch array (set once, at creation)
 
     // A slot whose device buffer holds `bytes` and whose pinned host buffer holds `host_bytes`
     // (0 = as large as the device buffer: only the part the host fills needs a pinned twin).
@@ -234,5 +268,14 @@ struct DeviceCtx {
 
 // Context of the calling thread's current device (created on first use).
 int current_ctx(DeviceCtx **out);
+
+// A host lane of `ctx` for the length of a scope.
+struct HostLaneLock {
+    HostLane *lane;
+    explicit HostLaneLock(DeviceCtx *ctx) : lane(ctx->lock_host_lane()) {}
+    ~HostLaneLock() { lane->mu.unlock(); }
+    HostLaneLock(const HostLaneLock &) = delete;
+    HostLaneLock &operator=(const HostLaneLock &) = delete;
+};
 
 }  // namespace zbra

@@ -144,7 +144,7 @@ class CopyWorkers {
     std::mutex grow_mu_;
 };
 
-// The pinned ring of one device context.  Used under the context's host_mu only.
+// A pinned ring of one host lane of a device context: used by the call that holds the lane.
 struct HostPipe {
     static size_t env_kb(const char *name, size_t dflt) {
         const char *e = std::getenv(name);
