@@ -13,9 +13,10 @@ sys.path.insert(0, ROOT)
 import numpy as np
 
 
-def craft(rng, max_log2):
+def craft(rng, max_log2, count=None):
     lg = int(rng.integers(0, max_log2 + 1))
-    count = int(rng.integers(1, (1 << lg) + 1))
+    if count is None:
+        count = int(rng.integers(1, (1 << lg) + 1))
     pick = rng.integers(0, 10)
     w = int(rng.integers(0, 32)) if pick < 6 else int(rng.integers(32, 72)) if pick < 9 else int(rng.integers(72, 256))
     mid = int(rng.integers(-(1 << 63), 1 << 63, dtype=np.int64)) if rng.integers(0, 2) else int(rng.integers(-1000, 1000))
@@ -34,7 +35,11 @@ def craft(rng, max_log2):
 def run_trial(torch, device, L, oc, seed, max_log2=22, max_arrays=60):
     rng = np.random.default_rng(seed)
     na = int(rng.integers(1, max_arrays + 1))
-    items = [craft(rng, max_log2) for _ in range(na)]
+    # a third of the trials: every array with the same count and element kind (equal tile counts:
+    # the tile kernel then finds a tile's array without the table)
+    equal = rng.integers(0, 3) == 0
+    same = int(rng.integers(1, (1 << int(rng.integers(0, max_log2 - 3))) + 1)) if equal else None
+    items = [craft(rng, max_log2, same) for _ in range(na)]
     budget = 1 << 26
     kept = []
     for e, c in items:
@@ -42,6 +47,8 @@ def run_trial(torch, device, L, oc, seed, max_log2=22, max_arrays=60):
             kept.append((e, c)); budget -= c
     items = kept
     kinds = [L.ELEM_U32 if rng.integers(0, 3) == 0 else L.ELEM_I64 for _ in items]
+    if equal:
+        kinds = [kinds[0]] * len(items)
     blob = bytearray()
     offs = []
     for e, _ in items:

@@ -97,12 +97,19 @@ def run_trial(torch, device, L, seed, max_log2, max_arrays, verbose=False):
     g = torch.Generator(device=dev)
     g.manual_seed(seed)
     pick = lambda hi: int(torch.randint(0, hi, (1,), generator=g, device=dev))  # noqa: E731
-    na = 1 + pick(max_arrays)
+    # shape of the trial: one array alone (the single-array launch sequence), arrays of one length
+    # (batches of equal tile counts find their array without the tile table), or ragged lengths
+    shape = ("single", "equal", "equal", "ragged", "ragged", "ragged")[pick(6)]
+    na = 1 if shape == "single" else 1 + pick(max_arrays)
     budget = 1 << 27                                        # values per trial
     cols, kinds = [], []
+    same_lg = 1 + pick(max_log2 if shape == "single" else max(1, max_log2 - 4))
+    same_n = max(1, (1 << same_lg) - pick(1 << max(0, same_lg - 1)))
     for _ in range(na):
         lg = 1 + pick(max_log2)
         n = max(1, (1 << lg) - pick(1 << max(0, lg - 1)))
+        if shape != "ragged":
+            n = same_n
         if n > budget:
             break
         budget -= n
@@ -130,7 +137,7 @@ def run_trial(torch, device, L, seed, max_log2, max_arrays, verbose=False):
     for i, (c, b, r) in enumerate(zip(cols, back, device.read_results(dres))):
         assert r.status == 0 and r.out_count == c.numel() and torch.equal(c, b), (seed, i, kinds[i])
     if verbose:
-        print(f"seed {seed}: {len(cols)} arrays, {sum(c.numel() for c in cols)} values ok", flush=True)
+        print(f"seed {seed}: {shape}, {len(cols)} arrays, {sum(c.numel() for c in cols)} values ok", flush=True)
     return len(cols)
 
 
