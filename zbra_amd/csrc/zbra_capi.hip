@@ -907,7 +907,22 @@ static int encode_batch_dev(DeviceCtx *ctx, const EncodeItem *items, size_t nd, 
                     if (same) per_array = (uint32_t)per;
                 }
                 const uint32_t chunked = (pack_xcd && (uint64_t)gp == ntiles && ntiles >= 64) ? 1u : 0u;
-                if (fold)
+                // all arrays u32 and of one length (the tag columns of equal Blocks), or a single u32 array:
+                // tiles of 4096 tags, numbered per array (ZBRA_HIP_PACK_U32=0: the generic kernel, A/B aid)
+                static const bool pack_u32_on = [] { const char *e = getenv("ZBRA_HIP_PACK_U32"); return !e || atoi(e) != 0; }();
+                bool all_u32 = pack_u32_on;
+                for (size_t i = 0; all_u32 && i < nd; i++) all_u32 = items[i].kind == ZBRA_ELEM_U32 && items[i].n == items[0].n;
+                const uint64_t per32 = (items[0].n + TILE32 - 1) / TILE32, ntiles32 = per32 * nd;
+                if (all_u32 && per32 <= 0xFFFFFFFFull && ntiles32 <= 0xFFFFFFFFull && ntiles32 <= pack_most) {
+                    const uint32_t ch32 = (pack_xcd && ntiles32 >= 64) ? 1u : 0u;
+                    const uint64_t inv32 = per32 > 1 ? ~0ull / per32 + 1 : 0;  // ceil(2^64 / per32); one tile per array needs none
+                    if (fold)
+                        hipLaunchKernelGGL(enc_pack_u32_kernel<true>, dim3((unsigned)ntiles32), dim3(THREADS), 0, stream, d_jobs, (uint32_t)per32, inv32,
+                                           ntiles32, ch32, d_results);
+                    else
+                        hipLaunchKernelGGL(enc_pack_u32_kernel<false>, dim3((unsigned)ntiles32), dim3(THREADS), 0, stream, d_jobs, (uint32_t)per32, inv32,
+                                           ntiles32, ch32, d_results);
+                } else if (fold)
                     hipLaunchKernelGGL(enc_pack_kernel<true>, dim3(gp), dim3(THREADS), 0, stream, d_jobs, d_ts, d_map, (uint32_t)nd, ntiles, chunked,
                                        0u, 0ull, d_results);
                 else

@@ -1502,13 +1502,14 @@ __global__ void enc_finalize_kernel(EncodeJob *__restrict__ jobs, uint32_t nd, z
 }
 
 // Bits [lo, lo + 32) of a tile's packed stream, lo possibly negative or past the end; zz holds
-// the tile's zig-zag values (0 past the last value).  inv = ceil(2^32 / w).
+// the tile's LEN zig-zag values (0 past the last value).  inv = ceil(2^32 / w).
+template <int LEN = TILE>
 __device__ __forceinline__ uint32_t stream_dword(const uint32_t *zz, int32_t lo, uint32_t w, uint64_t inv) {
     int32_t i, pos;  // value i starts at bit pos relative to lo
     if (lo <= 0) { i = 0; pos = -lo; }
     else { i = (int32_t)(((uint64_t)(uint32_t)lo * inv) >> 32); pos = i * (int32_t)w - lo; }
     uint32_t acc = 0;
-    while (pos < 32 && i < TILE) {
+    while (pos < 32 && i < LEN) {
         const uint32_t z = zz[i];
         acc |= pos >= 0 ? z << pos : z >> (-pos);
         pos += (int32_t)w;
@@ -1549,9 +1550,10 @@ __device__ __forceinline__ void stage_zigzag(const EncodeJob &job, uint64_t v0, 
 // busy (16-B chunks would leave most of them idle while the rest walk 32 / w values per dword,
 // four dwords each): the u32 tag column of the sum-typed table packs in 0.30 ms instead of 0.49.
 constexpr uint32_t NARROW_W = 8;
-__device__ __forceinline__ void pack_tile_narrow(const EncodeJob &job, uint32_t w, uint64_t v0, uint32_t nv, uint32_t *zz) {
+// The staged tile (LEN values in zz, the first nv of them real) written out at width w <= NARROW_W.
+template <int LEN>
+__device__ __forceinline__ void emit_tile_narrow(const EncodeJob &job, uint32_t w, uint64_t v0, uint32_t nv, const uint32_t *zz) {
     const uint32_t tid = threadIdx.x;
-    stage_zigzag(job, v0, nv, zz);
     const uintptr_t G = (uintptr_t)job.out + 13 + ((v0 * w) >> 3);
     const uint32_t nbytes = (nv * w + 7u) >> 3;
     const uintptr_t Gend = G + nbytes;
@@ -1562,7 +1564,7 @@ __device__ __forceinline__ void pack_tile_narrow(const EncodeJob &job, uint32_t 
     for (uint32_t d = tid; d < ndw; d += THREADS) {
         const int32_t lo = (int32_t)(d * 32u) - (int32_t)(off4 * 8u);
         uint32_t v;
-        if ((w & (w - 1)) == 0 && lo >= 0 && (uint32_t)lo + 32u <= (uint32_t)TILE * w) {
+        if ((w & (w - 1)) == 0 && lo >= 0 && (uint32_t)lo + 32u <= (uint32_t)LEN * w) {
             // Widths 1, 2, 4 and 8 (booleans, constant columns, enum tags): the dword's 32 / w values lie
             // wholly inside the tile and start where the dword does (lo is a multiple of 8), so they are
             // read sixteen or eight bytes at a time, without the loop: few lanes have a dword at the
@@ -1585,7 +1587,7 @@ __device__ __forceinline__ void pack_tile_narrow(const EncodeJob &job, uint32_t 
                 v = zz[i0] | zz[i0 + 1] << 8 | zz[i0 + 2] << 16 | zz[i0 + 3] << 24;
             }
         } else {
-            v = stream_dword(zz, lo, w, inv);
+            v = stream_dword<LEN>(zz, lo, w, inv);
         }
         const uintptr_t addr = G4 + (uintptr_t)d * 4;
         if (addr >= G && addr + 4 <= Gend) {
@@ -1598,12 +1600,17 @@ __device__ __forceinline__ void pack_tile_narrow(const EncodeJob &job, uint32_t 
             }
         }
     }
-    __syncthreads();
+    __syncthreads();  // a later tile of this workgroup restages
+}
+__device__ __forceinline__ void pack_tile_narrow(const EncodeJob &job, uint32_t w, uint64_t v0, uint32_t nv, uint32_t *zz) {
+    stage_zigzag(job, v0, nv, zz);
+    emit_tile_narrow<TILE>(job, w, v0, nv, zz);
 }
 
-__device__ __forceinline__ void pack_tile_packed(const EncodeJob &job, uint32_t w, uint64_t v0, uint32_t nv, uint32_t *zz) {
+// The staged tile written out at width NARROW_W < w < 32.
+template <int LEN>
+__device__ __forceinline__ void emit_tile_packed(const EncodeJob &job, uint32_t w, uint64_t v0, uint32_t nv, const uint32_t *zz) {
     const uint32_t tid = threadIdx.x;
-    stage_zigzag(job, v0, nv, zz);
     const uintptr_t G = (uintptr_t)job.out + 13 + ((v0 * w) >> 3);
     const uint32_t nbytes = (nv * w + 7u) >> 3;
     const uintptr_t Gend = G + nbytes;
@@ -1614,10 +1621,10 @@ __device__ __forceinline__ void pack_tile_packed(const EncodeJob &job, uint32_t 
     for (uint32_t c = tid; c < nchunks; c += THREADS) {
         const int32_t lo = (int32_t)(c * 128u) - (int32_t)(off * 8u);
         u32x4 v;
-        v.x = stream_dword(zz, lo, w, inv);
-        v.y = stream_dword(zz, lo + 32, w, inv);
-        v.z = stream_dword(zz, lo + 64, w, inv);
-        v.w = stream_dword(zz, lo + 96, w, inv);
+        v.x = stream_dword<LEN>(zz, lo, w, inv);
+        v.y = stream_dword<LEN>(zz, lo + 32, w, inv);
+        v.z = stream_dword<LEN>(zz, lo + 64, w, inv);
+        v.w = stream_dword<LEN>(zz, lo + 96, w, inv);
         const uintptr_t addr = G0 + (uintptr_t)c * 16;
         if (addr >= G && addr + 16 <= Gend) {
             __builtin_nontemporal_store(v, gptr_mut<u32x4>(addr));  // streamed out once: -2 % on the whole encode
@@ -1630,7 +1637,11 @@ __device__ __forceinline__ void pack_tile_packed(const EncodeJob &job, uint32_t 
             }
         }
     }
-    __syncthreads();
+    __syncthreads();  // a later tile of this workgroup restages
+}
+__device__ __forceinline__ void pack_tile_packed(const EncodeJob &job, uint32_t w, uint64_t v0, uint32_t nv, uint32_t *zz) {
+    stage_zigzag(job, v0, nv, zz);
+    emit_tile_packed<TILE>(job, w, v0, nv, zz);
 }
 
 // Raw fallback: zig-zag value i as u64 LE at payload + 8*i (compression.rs:143-149).  The tile's
@@ -1755,6 +1766,85 @@ __global__ __launch_bounds__(THREADS) void enc_pack_kernel(const EncodeJob *__re
         else if (w <= NARROW_W) pack_tile_narrow(job, w, v0, nv, zz);
         else pack_tile_raw(job, v0, nv, zz64);
     }
+}
+
+// The pack pass of a submission whose arrays are all u32 (enum tags) and equally long, or a single
+// one.  A tile of 2048 tags is 8 KiB of input: with one such tile per workgroup a CU has half the
+// bytes in flight that an int64 column gives it, and the pass read 2^29 tags at 4.2 TB/s where
+// int64 columns reach 6.  Here a workgroup takes 4096 consecutive tags of one array (16 KiB, four
+// 16-byte loads per lane) and works in 32 bits: below width 32 the delta to the midpoint fits an
+// int32, so zig-zag(v - mid) is computed on the low halves.  Tiles are numbered per array
+// (per_array of them each): no table.  Raw widths (a tag column spanning 2^31 or more) take the
+// generic raw routine, half a tile at a time.
+constexpr int TILE32 = 2 * TILE;
+template <bool FINALIZE>
+__global__ __launch_bounds__(THREADS) void enc_pack_u32_kernel(const EncodeJob *__restrict__ jobs, uint32_t per_array, uint64_t per_array_inv,
+                                                                uint64_t ntiles, uint32_t xcd_chunked, zbra_dev_result *results) {
+    __shared__ __attribute__((aligned(16))) uint64_t zz64[TILE];  // 4096 32-bit zig-zag values, or a raw half tile's 64-bit ones
+    uint32_t *zz = (uint32_t *)zz64;
+    const uint32_t tid = threadIdx.x;
+    const uint64_t t = xcd_chunked ? xcd_chunked_tile(blockIdx.x, ntiles) : blockIdx.x;
+    if (t >= ntiles) return;
+    // t / per_array by a multiply-high with ceil(2^64 / per_array) (exact below 2^32 tiles); one tile per array: t itself
+    const uint32_t a = FINALIZE ? 0u : per_array == 1 ? (uint32_t)t : (uint32_t)(((unsigned __int128)(uint32_t)t * per_array_inv) >> 64);
+    const EncodeJob &job = jobs[a];
+    uint32_t w = job.width;
+    const uint64_t ta = t - (uint64_t)a * per_array;
+    if (FINALIZE) {  // as in enc_pack_kernel<true>
+        if (job.need_or) w = width_of(job.or_bits);
+        const uint64_t packed_len = 1 + (w >= 32 ? job.n * 8 : (job.n * w + 7) / 8);
+        const bool fits = job.cap >= 12 + packed_len;
+        if (ta == 0 && tid == 0) {
+            zbra_dev_result r;
+            r.status = fits ? ZBRA_OK : ZBRA_ERR_CAPACITY; r.width = w; r.out_count = fits ? 12 + packed_len : 0;
+            r.midpoint = job.midpoint; r.packed_len = packed_len;
+            if (results) results[0] = r;
+            if (fits) {
+                const uint64_t m = (uint64_t)job.midpoint;
+                for (int b = 0; b < 8; b++) job.out[b] = (uint8_t)(m >> (8 * b));
+                const uint32_t pl = (uint32_t)packed_len;  // `as u32`, compression.rs:288
+                for (int b = 0; b < 4; b++) job.out[8 + b] = (uint8_t)(pl >> (8 * b));
+                job.out[12] = (uint8_t)w;
+            }
+        }
+        if (!fits) return;
+    } else if (w == WIDTH_SKIP) {
+        return;
+    }
+    const uint64_t v0 = ta * TILE32;
+    if (v0 >= job.n) return;  // (arrays of one tile count: cannot happen; kept as the guard of the loads below)
+    const uint64_t left = job.n - v0;
+    const uint32_t nv = left < (uint64_t)TILE32 ? (uint32_t)left : (uint32_t)TILE32;
+    if (w >= 32) {
+        pack_tile_raw(job, v0, nv < (uint32_t)TILE ? nv : (uint32_t)TILE, zz64);
+        if (nv > (uint32_t)TILE) pack_tile_raw(job, v0 + TILE, nv - TILE, zz64);
+        return;
+    }
+    const uint32_t mid = (uint32_t)(uint64_t)job.midpoint;  // the median of u32 values is one (or lies between two)
+    constexpr int Q = TILE32 / (THREADS * 4);  // 16-byte loads per lane
+    const ZBRA_GLOBAL uint32_t *src = gptr<uint32_t>(job.values) + v0;
+    u32x4 v[Q];
+    if (nv == (uint32_t)TILE32) {
+#pragma unroll
+        for (int q = 0; q < Q; ++q) v[q] = __builtin_nontemporal_load((const ZBRA_GLOBAL u32x4 *)src + q * THREADS + tid);
+    } else {
+#pragma unroll
+        for (int q = 0; q < Q; ++q) {
+            const uint32_t i = (uint32_t)q * THREADS * 4 + tid * 4;
+            v[q].x = i < nv ? src[i] : mid; v[q].y = i + 1 < nv ? src[i + 1] : mid;
+            v[q].z = i + 2 < nv ? src[i + 2] : mid; v[q].w = i + 3 < nv ? src[i + 3] : mid;  // mid -> zig-zag 0
+        }
+    }
+    auto zz32 = [mid](uint32_t x) { const uint32_t d = x - mid; return (d << 1) ^ (uint32_t)((int32_t)d >> 31); };
+#pragma unroll
+    for (int q = 0; q < Q; ++q) {
+        uint4 z;
+        z.x = zz32(v[q].x); z.y = zz32(v[q].y); z.z = zz32(v[q].z); z.w = zz32(v[q].w);
+        *(uint4 *)(zz + q * THREADS * 4 + tid * 4) = z;
+    }
+    __syncthreads();
+    if (w <= NARROW_W) emit_tile_narrow<TILE32>(job, w, v0, nv, zz);
+    else emit_tile_packed<TILE32>(job, w, v0, nv, zz);
 }
 
 }  // namespace zbra
