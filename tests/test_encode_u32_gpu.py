@@ -84,6 +84,56 @@ def test_bytes_guards_and_alignments(env):
                 assert (got[:pad_out] == 0xEE).all() and (got[pad_out + len(expect):] == 0xEE).all(), "wrote outside E"
 
 
+def _shapes(rng, n):
+    """u32 columns that take each route of the median selection: brackets of one, two and a few
+    keys, a bracket below 4096 keys, wide brackets (random and sorted, whose candidates are one
+    stretch of the array), a candidate list that overflows, a run of one value inside wide data."""
+    ar = np.arange(n, dtype=np.uint64)
+    u = rng.integers(0, 100, n)
+    return {
+        "one_key": np.where(u < 70, 5, rng.integers(0, 1 << 20, n)).astype(np.uint32),
+        "two_keys": rng.integers(1000, 1002, n).astype(np.uint32),
+        "few_keys": rng.choice(np.array([0, 1, 2, 7], dtype=np.uint32), n, p=[0.5, 0.25, 0.15, 0.1]),
+        "heavy_ends": np.where(u < 45, 0, np.where(u < 48, 1, np.where(u < 51, 2, 3))).astype(np.uint32),
+        "below_4096_keys": (3_000_000_000 + rng.integers(0, 3000, n)).astype(np.uint32),
+        "wide": rng.integers(0, 1 << 32, n, dtype=np.uint64).astype(np.uint32),
+        "wide_24": (1 << 30) + rng.integers(0, 1 << 24, n, dtype=np.uint64).astype(np.uint32),
+        "sorted": (ar * 1000 % (1 << 32)).astype(np.uint32) if n * 1000 < (1 << 32) else (ar * 3).astype(np.uint32),
+        "reversed": ((n - ar) * 7).astype(np.uint32),
+        "three_far": rng.choice(np.array([0, 1 << 31, (1 << 32) - 1], dtype=np.uint32), n),
+        "run_in_wide": np.where(u < 4, 2_000_000_000, rng.integers(0, 1 << 32, n, dtype=np.uint64)).astype(np.uint32),
+        "sawtooth": ((ar % 4096) * 17).astype(np.uint32),
+    }
+
+
+@pytest.mark.parametrize("n", [5000, 70001, (1 << 21) + 3])
+def test_every_selection_route_single_and_batched(env, n):
+    torch, device, oc, L = env
+    rng = np.random.default_rng(n + 1)
+    shapes = _shapes(rng, n)
+    expects = {k: oc.compress_int_array(v.astype(np.int64)) for k, v in shapes.items()}
+    for k, v in shapes.items():                                   # one array per call
+        r, got = _encode_one(torch, device, L, v, pad_in=1, pad_out=5)
+        e = expects[k]
+        assert r.status == 0 and r.out_count == len(e), (k, n)
+        assert r.midpoint == struct.unpack("<q", e[:8])[0] and r.width == e[12], (k, n, r.midpoint, r.width)
+        assert got[5:5 + len(e)].tobytes() == e, (k, n)
+    # all of them as one submission (equal lengths), then with a shorter array added (ragged: the
+    # generic pack kernel behind the u32 form of the bracket pass)
+    for extra in ([], [shapes["wide"][:n // 2 + 1]]):
+        cols = list(shapes.values()) + extra
+        want = [expects[k] for k in shapes] + [oc.compress_int_array(c.astype(np.int64)) for c in extra]
+        d_cols = [torch.from_numpy(c.view(np.int32).copy()).cuda() for c in cols]
+        outs = [torch.full((device.encode_bound(c.size) + 16,), 0xEE, dtype=torch.uint8, device="cuda") for c in cols]
+        res = device.new_results(len(cols), "cuda")
+        device.encode_batch_dev(device.make_encode_descs(
+            [(d.data_ptr(), c.size, o.data_ptr() + 1, device.encode_bound(c.size), L.ELEM_U32) for d, c, o in zip(d_cols, cols, outs)]), res)
+        for i, (o, e, r) in enumerate(zip(outs, want, device.read_results(res))):
+            got = o.cpu().numpy()
+            assert r.status == 0 and r.out_count == len(e), (i, n)
+            assert got[1:1 + len(e)].tobytes() == e and got[0] == 0xEE and (got[1 + len(e):] == 0xEE).all(), (i, n)
+
+
 def test_capacity_error_writes_nothing(env):
     torch, device, oc, L = env
     tags = np.random.default_rng(33).integers(0, 9, 50000, dtype=np.uint32)

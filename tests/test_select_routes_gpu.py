@@ -134,6 +134,10 @@ def test_shapes_on_the_other_routes(extra):
         "    for n in (t.N0, t.N0 + 1):\n"
         "        v = t._shape(name, n, 5)\n"
         "        assert zc.compress_int_array(v) == oc.compress_int_array(v), (name, n)\n"
+        "import test_encode_u32_gpu as tu\n"   # u32 arrays have a bracket pass and a pack kernel of their own
+        "for n in (70001, (1 << 20) + 3):\n"
+        "    for k, v in tu._shapes(np.random.default_rng(n), n).items():\n"
+        "        assert zc.compress_u32_array(v) == oc.compress_int_array(v.astype(np.int64)), (k, n)\n"
         "print('routes ok')\n")
     p = subprocess.run([sys.executable, "-c", code], env={**os.environ, **extra}, capture_output=True, text=True, timeout=280)
     assert p.returncode == 0 and "routes ok" in p.stdout, p.stdout[-1500:] + p.stderr[-1500:]

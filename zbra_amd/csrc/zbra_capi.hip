@@ -840,7 +840,14 @@ static int encode_batch_dev(DeviceCtx *ctx, const EncodeItem *items, size_t nd, 
         // atomics), so a batch's runs are kept at 32 tiles or more: 2^26 rows as 4 to 1024 arrays
         // took 183-208 us in this pass with 8192 workgroups of 4 tiles each, 100-114 us with 1024.
         const uint64_t batch_grid = ntiles / 32 < STREAM_GRID_CAP / 2 ? STREAM_GRID_CAP / 2 : ntiles / 32 < STREAM_GRID_CAP * 4 ? ntiles / 32 : STREAM_GRID_CAP * 4;
-        const unsigned gs = grid_for(ntiles, bracket_grid ? bracket_grid : nd == 1 ? STREAM_GRID_CAP / 2 : (unsigned)batch_grid);
+        // every array u32 (enum tags): the 32-bit form of the pass (ZBRA_HIP_BRACKET_U32=0: the generic one, A/B aid).
+        // Its tiles are half the bytes, so a run's end weighs twice as much: runs of 128 tiles or more
+        // (128 tag arrays of 2^22 rows: 0.904 ms for the encode with 8192 workgroups, 0.878 with 4096, 0.857 with 2048 or 1024).
+        static const bool bracket_u32_on = [] { const char *e = getenv("ZBRA_HIP_BRACKET_U32"); return !e || atoi(e) != 0; }();
+        bool bracket_u32 = bracket_u32_on;
+        for (size_t i = 0; bracket_u32 && i < nd; i++) bracket_u32 = items[i].kind == ZBRA_ELEM_U32;
+        const uint64_t batch_grid_u32 = ntiles / 128 < STREAM_GRID_CAP / 2 ? STREAM_GRID_CAP / 2 : ntiles / 128 < STREAM_GRID_CAP * 4 ? ntiles / 128 : STREAM_GRID_CAP * 4;
+        const unsigned gs = grid_for(ntiles, bracket_grid ? bracket_grid : nd == 1 ? STREAM_GRID_CAP / 2 : (unsigned)(bracket_u32 ? batch_grid_u32 : batch_grid));
         const unsigned ga = (unsigned)((nd + 255) / 256);
         // workgroups of a many-workgroup select level, dealt to the arrays it finds pending
         static const unsigned level_grid = [] { const char *e = getenv("ZBRA_HIP_LEVEL_GRID"); return e ? (unsigned)atol(e) : 0u; }();
@@ -856,8 +863,10 @@ static int encode_batch_dev(DeviceCtx *ctx, const EncodeItem *items, size_t nd, 
                                bracket ? 1u : 0u);
             // arrays outside the list (sorted whole by the sample kernel, or plain u64) need
             // neither the bracket pass nor any select launch
-            if (n_list)
-                hipLaunchKernelGGL(enc_bracket_kernel, dim3(gs), dim3(THREADS), 0, stream, d_jobs, d_ts, (uint32_t)nd, ntiles);
+            if (n_list) {
+                if (bracket_u32) hipLaunchKernelGGL(enc_bracket_u32_kernel, dim3(gs), dim3(THREADS), 0, stream, d_jobs, d_ts, (uint32_t)nd, ntiles);
+                else hipLaunchKernelGGL(enc_bracket_kernel, dim3(gs), dim3(THREADS), 0, stream, d_jobs, d_ts, (uint32_t)nd, ntiles);
+            }
         }
         hipLaunchKernelGGL(enc_setup_kernel, dim3((unsigned)nd), dim3(THREADS), 0, stream, d_jobs, (uint32_t)nd, d_pend, small_max,
                            d_ts, d_map, d_or_flag);

@@ -718,6 +718,249 @@ __global__ __launch_bounds__(THREADS, ZBRA_BRACKET_WAVES) void enc_bracket_kerne
     }
 }
 
+// ---- 2b. the same pass for submissions of u32 arrays only (enum tags) --------------------------
+//
+// A tile of 2048 tags is 8 KiB: at the four waves per SIMD the pass above runs with, a CU has half
+// the bytes in flight that int64 columns give it, and per value it does 64-bit compares on numbers
+// that have 32 bits (2^29 tags were read at 4.1 TB/s against 6.3-6.6 for int64 columns).  When the
+// host sees that every array of a submission is u32 it launches this kernel instead: the same
+// routes, counters and epilogues, but values stay 32 bits wide (the bracket's bounds are brought
+// into the u32 domain once per run: they are biased array elements, or "no bound"), a trip of the
+// tile loop loads TWO tiles before it looks at either, and candidates are staged as 32-bit words.
+struct BracketAcc32 {
+    uint32_t lo = ~0u, hi = 0, above = ~0u;
+    uint32_t any_above = 0;
+    uint32_t below = 0, inb = 0, first = 0;
+};
+constexpr int TAGS_PER_LANE = TILE / THREADS;  // 8: two 16-byte loads
+__device__ __forceinline__ void load_tile_u32(const void *values, uint64_t v0, uint64_t n, uint32_t fill, uint32_t (&x)[TAGS_PER_LANE]) {
+    const uint32_t tid = threadIdx.x;
+    static_assert(TAGS_PER_LANE == 8, "two 16-byte loads per lane");
+    if (v0 + TILE <= n) {
+        const ZBRA_GLOBAL u32x4 *src = (const ZBRA_GLOBAL u32x4 *)(gptr<uint32_t>(values) + v0) + tid;
+        const u32x4 a = __builtin_nontemporal_load(src), b = __builtin_nontemporal_load(src + THREADS);
+        x[0] = a.x; x[1] = a.y; x[2] = a.z; x[3] = a.w; x[4] = b.x; x[5] = b.y; x[6] = b.z; x[7] = b.w;
+    } else {
+#pragma unroll
+        for (int e = 0; e < TAGS_PER_LANE; ++e) {
+            const uint64_t i = v0 + tile_slot(ZBRA_ELEM_U32, e);
+            x[e] = i < n ? gptr<uint32_t>(values)[i] : fill;
+        }
+    }
+}
+// bracket_values for u32 values: lo32 / hi32 are the bracket in the u32 domain.
+template <uint32_t MODE, bool WHOLE, int E0, int E1>
+__device__ __forceinline__ void bracket_values_u32(const uint32_t (&x)[TAGS_PER_LANE], uint64_t v0, uint64_t n, uint32_t lo32, uint32_t hi32,
+                                                   BracketAcc32 &acc, uint32_t *lh, uint32_t *lcand, uint32_t *lcount,
+                                                   uint32_t digit_shift = 0, uint32_t *wave_cnt = nullptr, uint64_t lo_b = 0) {
+    uint64_t improves = 0;
+#pragma unroll
+    for (int e = E0; e < E1; ++e) improves |= __builtin_amdgcn_ballot_w64(x[e] < acc.lo) | __builtin_amdgcn_ballot_w64(x[e] > acc.hi);
+    if (improves != 0) {
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int e = E0; e < E1; ++e) { acc.lo = min(acc.lo, x[e]); acc.hi = max(acc.hi, x[e]); }
+    }
+#pragma unroll
+    for (int e = E0; e < E1; ++e) {
+        const uint32_t b = x[e];
+        if (MODE == SEL_BRACKET_COMPACT) {
+            const bool valid = WHOLE || v0 + tile_slot(ZBRA_ELEM_U32, e) < n;
+            const uint32_t r = b - lo32;
+            const bool inside = valid && r <= hi32 - lo32;
+            const uint64_t m = __builtin_amdgcn_ballot_w64(inside);
+            wave_cnt[0] += (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(valid && b < lo32));
+            wave_cnt[1] += (uint32_t)__popcll(m);
+            if (inside) {
+                lcand[*lcount + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u))] = b;
+                // first digit of the select's 64-bit key, (v ^ SIGN) - lo_b (a bracket without a lower bound has lo_b = 0)
+                atomicAdd(&lh[(uint32_t)((((uint64_t)b | SIGN) - lo_b) >> digit_shift)], 1u);
+            }
+            *lcount += (uint32_t)__popcll(m);
+        } else if (MODE != SEL_FULL) {
+            const bool valid = WHOLE || v0 + tile_slot(ZBRA_ELEM_U32, e) < n;
+            const bool is_below = valid && b < lo32, is_above = valid && b > hi32;
+            const bool inside = valid && !is_below && !is_above;
+            acc.below += is_below;
+            acc.inb += inside;
+            acc.any_above |= is_above;
+            acc.above = is_above && b < acc.above ? b : acc.above;
+            if (MODE == SEL_BRACKET_ONE) {
+            } else if (MODE == SEL_BRACKET_TWO) {
+                acc.first += inside && b == lo32;
+            } else if (MODE == SEL_BRACKET_MICRO) {
+                if (inside) lh[((b - lo32) & (MICRO_KEYS - 1)) * THREADS + threadIdx.x] += 1u;
+            } else if (inside) {
+                atomicAdd(&lh[b - lo32], 1u);
+            }
+        }
+    }
+}
+
+#ifndef ZBRA_BRACKET_U32_WAVES
+#define ZBRA_BRACKET_U32_WAVES 4
+#endif
+__global__ __launch_bounds__(THREADS, ZBRA_BRACKET_U32_WAVES) void enc_bracket_u32_kernel(EncodeJob *__restrict__ jobs,
+                                                                                       const uint64_t *__restrict__ tile_start, uint32_t nd,
+                                                                                       uint64_t ntiles) {
+    __shared__ uint32_t lh[BINS];
+    __shared__ __attribute__((aligned(16))) uint32_t lcand[CAND_LDS];
+    __shared__ unsigned long long lbelow, linb;
+    __shared__ uint32_t lfirst;
+    for (uint32_t b = threadIdx.x; b < BINS; b += THREADS) lh[b] = 0;
+    if (threadIdx.x == 0) { lbelow = 0; linb = 0; lfirst = 0; }
+    __syncthreads();
+    auto run = [&](uint32_t a, uint64_t a_first, uint64_t t0, uint64_t t1, uint64_t step) {
+        const EncodeJob &job = jobs[a];
+        if (job.mode == SEL_DONE) return;  // uniform
+        const uint64_t bspan = job.hi_b - job.lo_b;
+        const uint32_t mode = job.mode != SEL_BRACKET_HIST || bspan >= (uint64_t)MICRO_KEYS ? job.mode
+                              : bspan == 0 ? SEL_BRACKET_ONE : bspan == 1 ? SEL_BRACKET_TWO : SEL_BRACKET_MICRO;
+        const void *values = job.values;
+        const uint64_t n = job.n, seg_cap = job.seg_cap;
+        BracketCounters::Slot *ctr = &job.counters->slot[blockIdx.x % CAND_SEGS];
+        uint32_t flushes = 0;
+        // the bracket in the u32 domain: a bound is the biased image of an array element, or 0 / ~0 for "none"
+        const uint32_t lo32 = job.lo_b >= SIGN ? (uint32_t)(job.lo_b - SIGN) : 0u;
+        const uint32_t hi32 = job.hi_b < SIGN + 0x100000000ull ? (uint32_t)(job.hi_b - SIGN) : 0xFFFFFFFFu;
+        const uint64_t lo_b64 = job.lo_b;
+        const uint32_t fill = gptr<uint32_t>(values)[0];
+        BracketAcc32 acc;
+        acc.lo = (uint32_t)(__hip_atomic_load(&job.min_b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - SIGN);
+        acc.hi = (uint32_t)(__hip_atomic_load(&job.max_b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - SIGN);
+        constexpr uint32_t WAVES = THREADS / 64, WAVE_CAP = CAND_LDS / WAVES;
+        const uint32_t dsh = digit_shift(job.key_bits, 0);
+        const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+        uint32_t *wstage = lcand + wave * WAVE_CAP;
+        uint32_t wcount = 0;
+        uint32_t wcnt[2] = {0, 0};
+        auto flush_wave = [&]() {
+            if (wcount == 0) return;
+            const uint32_t sgm = (blockIdx.x * WAVES + wave + flushes++) % CAND_SEGS;
+            unsigned long long base = 0;
+            if (lane == 0) base = atomicAdd(&job.counters->slot[sgm].cand_count, (unsigned long long)wcount);
+            base = __shfl(base, 0);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            if (base + wcount <= seg_cap) {
+                ZBRA_GLOBAL int64_t *dst = gptr_mut<int64_t>(job.cand) + (size_t)sgm * seg_cap + base;
+                for (uint32_t i = lane; i < wcount; i += 64) dst[i] = (int64_t)wstage[i];  // the list holds int64 values
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __builtin_amdgcn_wave_barrier();
+            wcount = 0;
+        };
+        auto tile = [&](const uint32_t (&x)[TAGS_PER_LANE], uint64_t v0) {
+            const bool whole = v0 + TILE <= n;  // uniform
+            if (mode == SEL_BRACKET_HIST) {
+                if (whole) bracket_values_u32<SEL_BRACKET_HIST, true, 0, TAGS_PER_LANE>(x, v0, n, lo32, hi32, acc, lh, nullptr, nullptr);
+                else bracket_values_u32<SEL_BRACKET_HIST, false, 0, TAGS_PER_LANE>(x, v0, n, lo32, hi32, acc, lh, nullptr, nullptr);
+            } else if (mode == SEL_FULL) {
+                bracket_values_u32<SEL_FULL, true, 0, TAGS_PER_LANE>(x, v0, n, lo32, hi32, acc, lh, nullptr, nullptr);
+            } else if (mode == SEL_BRACKET_MICRO) {
+                if (whole) bracket_values_u32<SEL_BRACKET_MICRO, true, 0, TAGS_PER_LANE>(x, v0, n, lo32, hi32, acc, lh, nullptr, nullptr);
+                else bracket_values_u32<SEL_BRACKET_MICRO, false, 0, TAGS_PER_LANE>(x, v0, n, lo32, hi32, acc, lh, nullptr, nullptr);
+            } else if (mode == SEL_BRACKET_ONE) {
+                if (whole) bracket_values_u32<SEL_BRACKET_ONE, true, 0, TAGS_PER_LANE>(x, v0, n, lo32, hi32, acc, lh, nullptr, nullptr);
+                else bracket_values_u32<SEL_BRACKET_ONE, false, 0, TAGS_PER_LANE>(x, v0, n, lo32, hi32, acc, lh, nullptr, nullptr);
+            } else if (mode == SEL_BRACKET_TWO) {
+                if (whole) bracket_values_u32<SEL_BRACKET_TWO, true, 0, TAGS_PER_LANE>(x, v0, n, lo32, hi32, acc, lh, nullptr, nullptr);
+                else bracket_values_u32<SEL_BRACKET_TWO, false, 0, TAGS_PER_LANE>(x, v0, n, lo32, hi32, acc, lh, nullptr, nullptr);
+            } else {
+                // a wave appends at most TILE / 2 / WAVES values per half of a tile
+                static_assert(WAVE_CAP >= 2 * (TILE / 2 / WAVES), "room for two halves between looks");
+#define ZBRA_COMPACT_PART32(E0, E1)                                                                                                   \
+    if (wcount + TILE / 2 / WAVES > WAVE_CAP) flush_wave();                                                                            \
+    if (whole) bracket_values_u32<SEL_BRACKET_COMPACT, true, E0, E1>(x, v0, n, lo32, hi32, acc, lh, wstage, &wcount, dsh, wcnt, lo_b64); \
+    else bracket_values_u32<SEL_BRACKET_COMPACT, false, E0, E1>(x, v0, n, lo32, hi32, acc, lh, wstage, &wcount, dsh, wcnt, lo_b64);
+                ZBRA_COMPACT_PART32(0, 4)
+                ZBRA_COMPACT_PART32(4, 8)
+#undef ZBRA_COMPACT_PART32
+            }
+        };
+        // the same walk over the array's tiles as in enc_bracket_kernel (scattered inside a contiguous run)
+        const uint64_t T = (n + TILE - 1) / TILE;
+        uint64_t S = 0;
+        if (step == 1 && T > 512) S = T % 127 ? 127 : T % 131 ? 131 : T % 137 ? 137 : 139;
+        uint64_t q = S ? ((t0 - a_first) * S) % T : t0 - a_first;
+        auto next_q = [&]() { q = S ? (q + S >= T ? q + S - T : q + S) : q + step; };
+        for (uint64_t t = t0; t < t1;) {
+            // two tiles per trip, both tiles' loads issued before either is looked at
+            const uint64_t va = q * TILE;
+            next_q();
+            const bool pair = t + step < t1;  // uniform
+            const uint64_t vb = q * TILE;
+            uint32_t xa[TAGS_PER_LANE], xb[TAGS_PER_LANE];
+            load_tile_u32(values, va, n, fill, xa);
+            if (pair) { load_tile_u32(values, vb, n, fill, xb); next_q(); }
+            tile(xa, va);
+            if (pair) tile(xb, vb);
+            t += pair ? 2 * step : step;
+        }
+        uint32_t lo = acc.lo, hi = acc.hi;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { lo = min(lo, (uint32_t)__shfl_xor(lo, o)); hi = max(hi, (uint32_t)__shfl_xor(hi, o)); }
+        if (lane == 0) {
+            unsigned long long *pmin = (unsigned long long *)&jobs[a].min_b, *pmax = (unsigned long long *)&jobs[a].max_b;
+            const unsigned long long lo_b = SIGN + lo, hi_b = SIGN + hi;
+            if (lo_b < __hip_atomic_load(pmin, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMin(pmin, lo_b);
+            if (hi_b > __hip_atomic_load(pmax, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(pmax, hi_b);
+        }
+        if (mode != SEL_FULL) {
+            if (mode == SEL_BRACKET_COMPACT && lane == 0) { acc.below = wcnt[0]; acc.inb = wcnt[1]; }
+            if (acc.below) atomicAdd(&lbelow, (unsigned long long)acc.below);
+            if (acc.inb) atomicAdd(&linb, (unsigned long long)acc.inb);
+            const uint64_t above = wave_min_u64(acc.any_above ? SIGN + acc.above : ~0ull);
+            if (lane == 0) {
+                unsigned long long *pabove = (unsigned long long *)&jobs[a].next_above;
+                if (above < __hip_atomic_load(pabove, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMin(pabove, (unsigned long long)above);
+            }
+            if (mode == SEL_BRACKET_COMPACT) flush_wave();
+            if (mode == SEL_BRACKET_TWO) {
+                uint32_t c = acc.first;
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o);
+                if (lane == 0 && c) atomicAdd(&lfirst, c);
+            }
+            if (mode == SEL_BRACKET_MICRO) {
+#pragma unroll
+                for (uint32_t k = 0; k < MICRO_KEYS; k++) {
+                    uint32_t c = lh[k * THREADS + threadIdx.x];
+                    lh[k * THREADS + threadIdx.x] = 0;
+#pragma unroll
+                    for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o);
+                    if (lane == 0 && c) atomicAdd(&lh[MICRO_KEYS * THREADS + k], c);
+                }
+            }
+            __syncthreads();
+            if (mode == SEL_BRACKET_MICRO && threadIdx.x < MICRO_KEYS) {
+                const uint32_t c = lh[MICRO_KEYS * THREADS + threadIdx.x];
+                if (c) { atomicAdd(&job.hist[threadIdx.x], c); lh[MICRO_KEYS * THREADS + threadIdx.x] = 0; }
+            }
+            if (mode == SEL_BRACKET_HIST || mode == SEL_BRACKET_COMPACT) {
+                uint32_t *gh = job.hist;
+                for (uint32_t b = threadIdx.x; b < BINS; b += THREADS) {
+                    const uint32_t c = lh[b];
+                    if (c) { atomicAdd(&gh[b], c); lh[b] = 0; }
+                }
+            }
+            if (threadIdx.x == 0) {
+                if (lbelow) atomicAdd(&ctr->below, lbelow);
+                if (linb) atomicAdd(&ctr->inb, linb);
+                if (mode == SEL_BRACKET_TWO && lfirst) atomicAdd(&ctr->first, (unsigned long long)lfirst);
+                lbelow = 0; linb = 0; lfirst = 0;
+            }
+            __syncthreads();
+        }
+    };
+    if (nd == 1) {
+        if (blockIdx.x < ntiles) run(0, 0, blockIdx.x, ntiles, gridDim.x);
+    } else {
+        for_each_array_run(tile_start, nd, ntiles, [&](uint32_t a, uint64_t a_first, uint64_t t0, uint64_t t1) { run(a, a_first, t0, t1, 1); });
+    }
+}
+
 // ---- 3. verify the bracket, set up the radix select -------------------------------------------
 
 // The bin that holds rank k of a BINS-bin histogram, found by one workgroup of THREADS lanes: lane
