@@ -35,8 +35,7 @@ def craft(rng, max_log2, count=None):
 def run_trial(torch, device, L, oc, seed, max_log2=22, max_arrays=60):
     rng = np.random.default_rng(seed)
     na = int(rng.integers(1, max_arrays + 1))
-    # a third of the trials: every array with the same count and element kind (equal tile counts:
-    # the tile kernel then finds a tile's array without the table)
+    # a third of the trials: every array with the same count and element kind (the columns of equal Blocks)
     equal = rng.integers(0, 3) == 0
     same = int(rng.integers(1, (1 << int(rng.integers(0, max_log2 - 3))) + 1)) if equal else None
     items = [craft(rng, max_log2, same) for _ in range(na)]

@@ -98,7 +98,7 @@ def run_trial(torch, device, L, seed, max_log2, max_arrays, verbose=False):
     g.manual_seed(seed)
     pick = lambda hi: int(torch.randint(0, hi, (1,), generator=g, device=dev))  # noqa: E731
     # shape of the trial: one array alone (the single-array launch sequence), arrays of one length
-    # (batches of equal tile counts find their array without the tile table), or ragged lengths
+    # (u32 arrays of one length are packed by a kernel that numbers its tiles per array), or ragged lengths
     shape = ("single", "equal", "equal", "ragged", "ragged", "ragged")[pick(6)]
     na = 1 if shape == "single" else 1 + pick(max_arrays)
     budget = 1 << 27                                        # values per trial

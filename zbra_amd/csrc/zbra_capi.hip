@@ -98,15 +98,12 @@ static uint64_t launch_limit();
 
 template <int DT, int TH>
 static void launch_decode_t(const DecodeConfig &c, hipStream_t stream, const DecodePlan *plans, const uint64_t *ts,
-                            const uint32_t *tmap, uint32_t nd, uint64_t first_tile, uint64_t all_tiles, uint32_t order, uint32_t per_array) {
+                            const uint32_t *tmap, uint32_t nd, uint64_t first_tile, uint64_t all_tiles, uint32_t order) {
     // c.xcd: 2 = the order the caller worked out (decode_tile_order); anything else forces that order (tuning)
     const uint32_t want = c.xcd == 2 ? order : (uint32_t)c.xcd;
     // tiles per launch: a multiple of 8 (whole rounds of the XCDs) within the dispatch limit
     uint64_t per = launch_limit() / TH & ~7ull;
     if (per == 0) per = 8;
-    // ceil(2^64 / per_array): the kernel's multiply-high in place of a division (per_array >= 1; for 1 the quotient is t itself)
-    const uint64_t per_inv = per_array > 1 ? ~0ull / per_array + 1 : 0;
-    if (per_array == 1 || first_tile + all_tiles > 0xFFFFFFFFull) per_array = 0;  // the table serves these
     for (uint64_t done = 0; done < all_tiles; done += per) {
         const uint64_t base = first_tile + done;
         const uint64_t ntiles = all_tiles - done < per ? all_tiles - done : per;
@@ -123,7 +120,7 @@ static void launch_decode_t(const DecodeConfig &c, hipStream_t stream, const Dec
         const dim3 g(grid), b(TH);
         const uint32_t x = ((uint64_t)grid == ntiles && ntiles >= 64) ? want : 0u;
 #define ZBRA_LAUNCH_DECODE(NTV, DIR) \
-    hipLaunchKernelGGL((decode_tiles_kernel<DT, TH, NTV, DIR>), g, b, 0, stream, plans, ts, tmap, nd, base, ntiles, x, per_array, per_inv)
+    hipLaunchKernelGGL((decode_tiles_kernel<DT, TH, NTV, DIR>), g, b, 0, stream, plans, ts, tmap, nd, base, ntiles, x)
         switch ((c.nt & 3) * 2 + (c.direct == 1 ? 1 : 0)) {
             case 0: ZBRA_LAUNCH_DECODE(0, false); break;
             case 1: ZBRA_LAUNCH_DECODE(0, true); break;
@@ -139,7 +136,7 @@ static void launch_decode_t(const DecodeConfig &c, hipStream_t stream, const Dec
 }
 
 typedef void (*DecodeLauncher)(const DecodeConfig &, hipStream_t, const DecodePlan *, const uint64_t *, const uint32_t *,
-                               uint32_t, uint64_t, uint64_t, uint32_t, uint32_t);
+                               uint32_t, uint64_t, uint64_t, uint32_t);
 struct DecodeShape { int tile, threads; DecodeLauncher fn; };
 static const DecodeShape kDecodeShapes[] = {  // the default and the alternatives it was measured against
     {2048, 512, launch_decode_t<2048, 512>}, {2048, 256, launch_decode_t<2048, 256>}, {1024, 256, launch_decode_t<1024, 256>},
@@ -237,21 +234,10 @@ static inline uint32_t decode_tile_order(uint64_t encoded_bytes, uint64_t values
 }
 
 static void launch_decode(hipStream_t stream, const DecodePlan *plans, const uint64_t *ts, const uint32_t *tmap, uint32_t nd,
-                          uint64_t ntiles, uint32_t order, uint32_t per_array = 0) {
+                          uint64_t ntiles, uint32_t order) {
     const Tuning &t = tuning();
-    t.decode_fn(t.decode, stream, plans, ts, tmap, nd, 0, ntiles, order, per_array);
+    t.decode_fn(t.decode, stream, plans, ts, tmap, nd, 0, ntiles, order);
 }
-// The tiles every array of a submission has, if they all have the same number (and more than one array); else 0.
-static uint32_t uniform_tiles(const zbra_array_desc *descs, size_t nd) {
-    static const bool off = [] { const char *e = getenv("ZBRA_HIP_DECODE_UNIFORM"); return e && atoi(e) == 0; }();  // A/B aid
-    if (nd < 2 || off) return 0;
-    const uint64_t per = decode_tiles_of(descs[0].count, descs[0].kind);
-    if (per == 0 || per > 0xFFFFFFFFull) return 0;
-    for (size_t i = 1; i < nd; i++)
-        if (decode_tiles_of(descs[i].count, descs[i].kind) != per) return 0;
-    return (uint32_t)per;
-}
-
 // Narrow submissions (every array at most Tuning::warm_bits encoded bits per value, warm_min_bytes or more
 // in all) are decoded in chunks of about warm_bytes packed bytes: warm_tiles_kernel reads a
 // chunk's packed bytes into the memory-side cache, then the tile kernel decodes it with plain
@@ -300,11 +286,11 @@ static WarmPlan warm_plan_for(const zbra_array_desc *descs, size_t nd, uint64_t 
 // Tile kernel launches of one submission: all its tiles at once, or chunk by chunk behind the
 // warm-up of each chunk.
 static void launch_decode_submission(hipStream_t stream, const DecodePlan *plans, const uint64_t *ts, const uint32_t *tmap, uint32_t nd,
-                                     uint64_t first, uint64_t ntiles, uint32_t order, const WarmPlan &wp, uint32_t per_array = 0) {
+                                     uint64_t first, uint64_t ntiles, uint32_t order, const WarmPlan &wp) {
     const Tuning &t = tuning();
     DecodeConfig c = t.decode;
     if (!wp.on) {
-        t.decode_fn(c, stream, plans, ts, tmap, nd, first, ntiles, order, per_array);
+        t.decode_fn(c, stream, plans, ts, tmap, nd, first, ntiles, order);
         return;
     }
     c.nt = 2;      // plain loads (they hit what the warm-up left), nontemporal stores
@@ -314,7 +300,7 @@ static void launch_decode_submission(hipStream_t stream, const DecodePlan *plans
         const unsigned grid = (unsigned)((n + wp.tiles_per_wg - 1) / wp.tiles_per_wg);
         hipLaunchKernelGGL((warm_tiles_kernel<2048>), dim3(grid), dim3(256), 0, stream, plans, ts, tmap, nd, first + done, n, wp.tiles_per_wg,
                            t.warm_bits > 31 ? 31u : t.warm_bits);
-        t.decode_fn(c, stream, plans, ts, tmap, nd, first + done, n, order, per_array);
+        t.decode_fn(c, stream, plans, ts, tmap, nd, first + done, n, order);
     }
 }
 
@@ -435,7 +421,7 @@ static int decode_batch_dev(DeviceCtx *ctx, const zbra_array_desc *descs, size_t
                            d_plans, d_map, d_results, d_orig);
         if (ntiles && !mixed) {
             launch_decode_submission(stream, d_plans, d_ts, d_map, (uint32_t)nd, 0, ntiles, decode_tile_order(all_bytes, all_values, nd),
-                                     all_narrow ? warm_plan_of(ntiles, all_bytes) : WarmPlan(), uniform_tiles(descs, nd));
+                                     all_narrow ? warm_plan_of(ntiles, all_bytes) : WarmPlan());
         } else if (ntiles) {
             launch_decode_submission(stream, d_plans, d_ts, d_map, (uint32_t)nd, 0, n_tiles, decode_tile_order(n_bytes, n_values, n_narrow),
                                      warm_plan_of(n_tiles, n_bytes));
@@ -696,7 +682,7 @@ static int decode_batch_dev_noalloc(DeviceCtx *ctx, const zbra_array_desc *descs
         hipLaunchKernelGGL(plan_decode_noalloc_kernel, dim3(n), dim3(256), 0, stream, c, (uint32_t)first, n, sc->plans, sc->tile_start,
                            sc->tile_map, d_results);
     }
-    if (ntiles) launch_decode(stream, sc->plans, sc->tile_start, sc->tile_map, (uint32_t)nd, ntiles, decode_tile_order(all_bytes, all_values, nd), uniform_tiles(descs, nd));
+    if (ntiles) launch_decode(stream, sc->plans, sc->tile_start, sc->tile_map, (uint32_t)nd, ntiles, decode_tile_order(all_bytes, all_values, nd));
     return hip_status(hipGetLastError());
 }
 
@@ -907,14 +893,6 @@ static int encode_batch_dev(DeviceCtx *ctx, const EncodeItem *items, size_t nd, 
                 const unsigned gp = grid_for(ntiles, (uint64_t)pack_grid_cap() < pack_most ? pack_grid_cap() : (unsigned)pack_most);
                 static const int pack_xcd_env = [] { const char *e = getenv("ZBRA_HIP_PACK_XCD"); return e ? atoi(e) : -1; }();
                 const bool pack_xcd = pack_xcd_env >= 0 ? pack_xcd_env != 0 : nd > 1;
-                // every array with the same number of tiles (Blocks of equal row counts): no tile -> array table read
-                uint32_t per_array = 0;
-                if (nd > 1 && ntiles <= 0xFFFFFFFFull) {
-                    const uint64_t per = tiles_of(items[0].n);
-                    bool same = per > 1 && per <= 0xFFFFFFFFull;
-                    for (size_t i = 1; same && i < nd; i++) same = tiles_of(items[i].n) == per;
-                    if (same) per_array = (uint32_t)per;
-                }
                 const uint32_t chunked = (pack_xcd && (uint64_t)gp == ntiles && ntiles >= 64) ? 1u : 0u;
                 // all arrays u32 and of one length (the tag columns of equal Blocks), or a single u32 array:
                 // tiles of 4096 tags, numbered per array (ZBRA_HIP_PACK_U32=0: the generic kernel, A/B aid)
@@ -933,10 +911,10 @@ static int encode_batch_dev(DeviceCtx *ctx, const EncodeItem *items, size_t nd, 
                                            ntiles32, ch32, d_results);
                 } else if (fold)
                     hipLaunchKernelGGL(enc_pack_kernel<true>, dim3(gp), dim3(THREADS), 0, stream, d_jobs, d_ts, d_map, (uint32_t)nd, ntiles, chunked,
-                                       0u, 0ull, d_results);
+                                       d_results);
                 else
                     hipLaunchKernelGGL(enc_pack_kernel<false>, dim3(gp), dim3(THREADS), 0, stream, d_jobs, d_ts, d_map, (uint32_t)nd, ntiles, chunked,
-                                       per_array, per_array ? ~0ull / per_array + 1 : 0ull, d_results);
+                                       d_results);
             }
         } else {
             hipLaunchKernelGGL(enc_report_median_kernel, dim3(ga), dim3(256), 0, stream, d_jobs, (uint32_t)nd, d_results);

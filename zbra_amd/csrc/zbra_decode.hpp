@@ -453,33 +453,20 @@ __global__ __launch_bounds__(256) void warm_tiles_kernel(const DecodePlan *__res
 // Batched submission: plans come from plan_decode_batch_kernel.  A launch covers the tiles
 // [tile_base, tile_base + ntiles) of the submission: the host cuts a submission whose one
 // workgroup per tile would pass the 2^32 work-items of a dispatch into several launches.
-// per_array: 0, or the number of tiles EVERY array of the submission has (Blocks of equal row counts:
-// the usual file).  Then tile t belongs to array t / per_array and nothing is looked up: with the
-// table, a workgroup's plan load waits for its table load, and that second memory latency in front
-// of every 16 KiB tile cost a batch of narrow arrays 4 % (2^29 u32 tags as 128 arrays: 422 against
-// 403 us for the same tags as one array).
 template <int DT, int TH, int NT, bool DIRECT>
 __global__ __launch_bounds__(TH) void decode_tiles_kernel(const DecodePlan *__restrict__ plans,
                                                           const uint64_t *__restrict__ tile_start,
                                                           const uint32_t *__restrict__ tile_map, uint32_t nd,
-                                                          uint64_t tile_base, uint64_t ntiles, uint32_t xcd_chunked, uint32_t per_array,
-                                                          uint64_t per_array_inv) {
+                                                          uint64_t tile_base, uint64_t ntiles, uint32_t xcd_chunked) {
     // u32 outputs are half as wide, so their tiles hold twice the values (same bytes written)
     __shared__ __attribute__((aligned(16))) uint32_t lds[lds_dwords<2 * DT>()];
     // xcd_chunked implies gridDim.x == ntiles: exactly one trip through the loop
     uint64_t i = xcd_chunked == 1 ? xcd_chunked_tile(blockIdx.x, ntiles) : xcd_chunked ? xcd_grouped_tile(blockIdx.x, ntiles, xcd_chunked) : blockIdx.x;
     for (; i < ntiles; i += gridDim.x) {
         const uint64_t t = tile_base + i;
-        if (per_array) {  // uniform
-            // t / per_array without a division: per_array_inv = ceil(2^64 / per_array), exact for t < 2^32
-            const uint32_t a = (uint32_t)(((unsigned __int128)(uint32_t)t * per_array_inv) >> 64);
-            const DecodePlan p = plans[a];
-            decode_tile<DT, TH, NT, DIRECT>(p, t - (uint64_t)a * per_array, lds);
-        } else {
-            const uint32_t a = nd > 1 ? tile_map[t] : 0;
-            const DecodePlan p = plans[a];
-            decode_tile<DT, TH, NT, DIRECT>(p, t - tile_start[a], lds);
-        }
+        const uint32_t a = nd > 1 ? tile_map[t] : 0;
+        const DecodePlan p = plans[a];
+        decode_tile<DT, TH, NT, DIRECT>(p, t - tile_start[a], lds);
     }
 }
 

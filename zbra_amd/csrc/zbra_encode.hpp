@@ -1960,9 +1960,6 @@ __global__ void enc_report_median_kernel(const EncodeJob *__restrict__ jobs, uin
     results[a] = r;
 }
 
-// per_array / per_array_inv: as in the decode tile kernel: when every array of the submission has
-// the same number of tiles, tile t belongs to array t / per_array (a multiply-high by
-// ceil(2^64 / per_array), exact below 2^32 tiles) and the table is not read.
 // FINALIZE (a single array with values, not framed): no enc_finalize_kernel ran before this launch.
 // Every workgroup derives the width and the capacity check itself (a few scalar operations on the
 // job it loads anyway), and the workgroup of tile 0 writes the 13 header bytes and the result words:
@@ -1971,14 +1968,13 @@ template <bool FINALIZE>
 __global__ __launch_bounds__(THREADS) void enc_pack_kernel(const EncodeJob *__restrict__ jobs,
                                                             const uint64_t *__restrict__ tile_start,
                                                             const uint32_t *__restrict__ tile_map, uint32_t nd,
-                                                            uint64_t ntiles, uint32_t xcd_chunked, uint32_t per_array, uint64_t per_array_inv,
-                                                            zbra_dev_result *results) {
+                                                            uint64_t ntiles, uint32_t xcd_chunked, zbra_dev_result *results) {
     __shared__ __attribute__((aligned(16))) uint64_t zz64[TILE];  // 64-bit zig-zag values of a raw tile; the packed paths use half of it
     uint32_t *zz = (uint32_t *)zz64;
     // xcd_chunked implies gridDim.x == ntiles: exactly one trip through the loop
     uint64_t t = xcd_chunked ? xcd_chunked_tile(blockIdx.x, ntiles) : blockIdx.x;
     for (; t < ntiles; t += gridDim.x) {
-        const uint32_t a = FINALIZE ? 0u : per_array ? (uint32_t)(((unsigned __int128)(uint32_t)t * per_array_inv) >> 64) : nd > 1 ? tile_map[t] : 0;
+        const uint32_t a = nd > 1 ? tile_map[t] : 0;
         const EncodeJob &job = jobs[a];
         uint32_t w = job.width;
         if (FINALIZE) {  // what enc_finalize_kernel does for an array with values
@@ -2002,7 +1998,7 @@ __global__ __launch_bounds__(THREADS) void enc_pack_kernel(const EncodeJob *__re
         } else if (w == WIDTH_SKIP) {
             continue;
         }
-        const uint64_t v0 = (per_array ? t - (uint64_t)a * per_array : t - tile_start[a]) * TILE;
+        const uint64_t v0 = (t - tile_start[a]) * TILE;
         const uint64_t left = job.n - v0;
         const uint32_t nv = left < (uint64_t)TILE ? (uint32_t)left : (uint32_t)TILE;
         if (w - (NARROW_W + 1) < 31u - NARROW_W) pack_tile_packed(job, w, v0, nv, zz);  // NARROW_W < w < 32
