@@ -100,6 +100,9 @@ def run_trial(torch, device, L, seed, max_log2, max_arrays, verbose=False):
     # shape of the trial: one array alone (the single-array launch sequence), arrays of one length
     # (u32 arrays of one length are packed by a kernel that numbers its tiles per array), or ragged lengths
     shape = ("single", "equal", "equal", "ragged", "ragged", "ragged")[pick(6)]
+    # a quarter of the trials hold u32 arrays only (enum tags, or any u32 column): such submissions
+    # have a bracket pass and, when single or of one length, a pack kernel of their own
+    all_u32 = pick(4) == 0
     na = 1 if shape == "single" else 1 + pick(max_arrays)
     budget = 1 << 27                                        # values per trial
     cols, kinds = [], []
@@ -115,7 +118,9 @@ def run_trial(torch, device, L, seed, max_log2, max_arrays, verbose=False):
         budget -= n
         k = KINDS[pick(len(KINDS))]
         v = make_array(torch, g, dev, k, n)
-        if k in ("two",) and pick(2):
+        if all_u32:
+            v = (((v & 0xFFFFFFFF) ^ 0x80000000) - 0x80000000).to(torch.int32)   # the low 32 bits as a u32 pattern
+        elif k in ("two",) and pick(2):
             v = v.to(torch.int32)                           # enum tags
         cols.append(v)
         kinds.append(k)
@@ -126,7 +131,7 @@ def run_trial(torch, device, L, seed, max_log2, max_arrays, verbose=False):
     device.encode_batch_dev(edesc, res)
     rs = device.read_results(res)
     for i, (c, r) in enumerate(zip(cols, rs)):
-        mid, w = expected(torch, c.to(torch.int64))
+        mid, w = expected(torch, c.to(torch.int64) & 0xFFFFFFFF if c.dtype == torch.int32 else c)
         assert r.status == 0 and r.midpoint == mid and r.width == w, (seed, i, kinds[i], c.numel(), r.status, r.midpoint, mid, r.width, w)
         n = c.numel()
         assert r.out_count == 13 + (8 * n if w >= 32 else (n * w + 7) // 8)
@@ -137,7 +142,7 @@ def run_trial(torch, device, L, seed, max_log2, max_arrays, verbose=False):
     for i, (c, b, r) in enumerate(zip(cols, back, device.read_results(dres))):
         assert r.status == 0 and r.out_count == c.numel() and torch.equal(c, b), (seed, i, kinds[i])
     if verbose:
-        print(f"seed {seed}: {shape}, {len(cols)} arrays, {sum(c.numel() for c in cols)} values ok", flush=True)
+        print(f"seed {seed}: {shape}{' u32' if all_u32 else ''}, {len(cols)} arrays, {sum(c.numel() for c in cols)} values ok", flush=True)
     return len(cols)
 
 
