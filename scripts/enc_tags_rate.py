@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Encode time of enum tag columns (u32, tags {0,1,2,7} at 50/25/15/10 %): 128 arrays of 2^22 rows
-in one submission, and one array of 2^29 rows."""
+in one submission, and one array of 2^29 rows.  With the argument `wide`: 30 random bits per value."""
 import os
 import sys
 
@@ -15,6 +15,8 @@ n_all = 1 << 29
 u = workloads.sm(0x5EED0004, torch.arange(n_all, dtype=torch.int64, device=dev)) % 100
 tags = torch.where(u < 50, 0, torch.where(u < 75, 1, torch.where(u < 90, 2, 7))).to(torch.int32)
 del u
+if len(sys.argv) > 1 and sys.argv[1] == "wide":  # a u32 column of 30 random bits instead: the wide-bracket route
+    tags = (workloads.sm(0x5EED0104, torch.arange(n_all, dtype=torch.int64, device=dev)) & 0x3FFFFFFF).to(torch.int32)
 
 
 def timed(fn):
