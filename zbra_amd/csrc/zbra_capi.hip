@@ -341,6 +341,38 @@ static unsigned pack_grid_cap() {
 
 // ---- decode, device-resident ---------------------------------------------------------------
 
+// Up to NOALLOC_CHUNK descriptors and their tile scan travel in the kernel arguments (about 3 KB),
+// so nothing is staged in pinned memory and no copy is enqueued: the call is kernel launches only.
+constexpr uint32_t NOALLOC_CHUNK = 64;
+struct NoAllocChunk {
+    zbra_array_desc d[NOALLOC_CHUNK];
+    uint64_t ts[NOALLOC_CHUNK + 1];  // tile_start of the chunk's arrays and of the one after
+};
+
+// Workgroup b handles array first + b of the submission: header parse, its tile_start entry (the
+// last workgroup also writes the entry after it) and its slice of the tile -> array table.
+__global__ __launch_bounds__(256) void plan_decode_noalloc_kernel(NoAllocChunk c, uint32_t first, uint32_t n, DecodePlan *__restrict__ plans,
+                                                                  uint64_t *__restrict__ tile_start, uint32_t *__restrict__ tile_map,
+                                                                  zbra_dev_result *results) {
+    const uint32_t b = blockIdx.x;
+    if (b >= n) return;
+    const uint32_t a = first + b;
+    const uint64_t t0 = c.ts[b], t1 = c.ts[b + 1];
+    if (threadIdx.x == 0) {
+        plan_one(c.d[b], plans + a, results ? results + a : nullptr);
+        tile_start[a] = t0;
+        if (b == n - 1) tile_start[a + 1] = t1;
+    }
+    for (uint64_t t = t0 + threadIdx.x; t < t1; t += blockDim.x) tile_map[t] = a;
+}
+
+
+// ZBRA_HIP_SMALL_BATCH_ARGS=0: small batches stage their table like large ones (A/B aid)
+static bool small_batch_args() {
+    static const bool on = [] { const char *e = getenv("ZBRA_HIP_SMALL_BATCH_ARGS"); return !e || atoi(e) != 0; }();
+    return on;
+}
+
 static int decode_batch_dev(DeviceCtx *ctx, const zbra_array_desc *descs, size_t nd, zbra_dev_result *d_results,
                             hipStream_t stream) {
     if (nd == 0) return ZBRA_OK;
@@ -386,6 +418,30 @@ static int decode_batch_dev(DeviceCtx *ctx, const zbra_array_desc *descs, size_t
     const bool all_narrow = route && warm_plan_for(descs, nd, ntiles, all_bytes).on;
     // worth its two extra launches only when the narrow arrays are a fair share of the work (a quarter of the tiles)
     const bool mixed = !all_narrow && n_narrow && n_bytes >= tuning().warm_min_bytes && n_tiles * 4 >= ntiles;
+    if (nd <= NOALLOC_CHUNK && !mixed && small_batch_args()) {
+        // A Block's worth of arrays: descriptors and tile scan travel in the plan kernel's arguments
+        // (as in the entry point that allocates nothing), so no table is staged in pinned memory and no
+        // copy sits in front of the kernels; the workspace slot only lends device memory.
+        const size_t off_ts_s = align_up(nd * sizeof(DecodePlan), 64);
+        const size_t off_map_s = align_up(off_ts_s + (nd + 1) * sizeof(uint64_t), 64);
+        Slot *s;
+        ZBRA_TRY(ctx->acquire(off_map_s + ntiles * sizeof(uint32_t), &s, 64));
+        DecodePlan *d_plans = (DecodePlan *)s->dev;
+        uint64_t *d_ts = (uint64_t *)((char *)s->dev + off_ts_s);
+        uint32_t *d_map = (uint32_t *)((char *)s->dev + off_map_s);
+        NoAllocChunk c;
+        uint64_t run = 0;
+        for (uint32_t b = 0; b < (uint32_t)nd; b++) { c.d[b] = descs[b]; c.ts[b] = run; run += decode_tiles_of(descs[b].count, descs[b].kind); }
+        c.ts[nd] = run;
+        for (uint32_t b = (uint32_t)nd; b < NOALLOC_CHUNK; b++) { std::memset(&c.d[b], 0, sizeof(c.d[b])); c.ts[b + 1] = run; }
+        hipLaunchKernelGGL(plan_decode_noalloc_kernel, dim3((unsigned)nd), dim3(256), 0, stream, c, 0u, (uint32_t)nd, d_plans, d_ts, d_map, d_results);
+        if (ntiles)
+            launch_decode_submission(stream, d_plans, d_ts, d_map, (uint32_t)nd, 0, ntiles, decode_tile_order(all_bytes, all_values, nd),
+                                     all_narrow ? warm_plan_of(ntiles, all_bytes) : WarmPlan());
+        int st = hip_status(hipGetLastError());
+        int st2 = ctx->release(s, stream);
+        return st != ZBRA_OK ? st : st2;
+    }
     const size_t off_ts = align_up(nd * sizeof(zbra_array_desc), 64);
     const size_t off_orig = align_up(off_ts + (nd + 1) * sizeof(uint64_t), 64);       // caller's index of each array (mixed only)
     const size_t host_bytes = off_orig + (mixed ? nd * sizeof(uint32_t) : 0);
@@ -623,31 +679,6 @@ static int enum_rows_batch_dev(DeviceCtx *ctx, const zbra_enum_desc *descs, size
 }
 
 // ---- decode, device-resident, no allocation --------------------------------------------------
-
-// Up to NOALLOC_CHUNK descriptors and their tile scan travel in the kernel arguments (about 3 KB),
-// so nothing is staged in pinned memory and no copy is enqueued: the call is kernel launches only.
-constexpr uint32_t NOALLOC_CHUNK = 64;
-struct NoAllocChunk {
-    zbra_array_desc d[NOALLOC_CHUNK];
-    uint64_t ts[NOALLOC_CHUNK + 1];  // tile_start of the chunk's arrays and of the one after
-};
-
-// Workgroup b handles array first + b of the submission: header parse, its tile_start entry (the
-// last workgroup also writes the entry after it) and its slice of the tile -> array table.
-__global__ __launch_bounds__(256) void plan_decode_noalloc_kernel(NoAllocChunk c, uint32_t first, uint32_t n, DecodePlan *__restrict__ plans,
-                                                                  uint64_t *__restrict__ tile_start, uint32_t *__restrict__ tile_map,
-                                                                  zbra_dev_result *results) {
-    const uint32_t b = blockIdx.x;
-    if (b >= n) return;
-    const uint32_t a = first + b;
-    const uint64_t t0 = c.ts[b], t1 = c.ts[b + 1];
-    if (threadIdx.x == 0) {
-        plan_one(c.d[b], plans + a, results ? results + a : nullptr);
-        tile_start[a] = t0;
-        if (b == n - 1) tile_start[a + 1] = t1;
-    }
-    for (uint64_t t = t0 + threadIdx.x; t < t1; t += blockDim.x) tile_map[t] = a;
-}
 
 static int decode_batch_dev_noalloc(DeviceCtx *ctx, const zbra_array_desc *descs, size_t nd, zbra_dev_result *d_results,
                                     hipStream_t stream) {
