@@ -196,12 +196,15 @@ def rendezvous_env():
 
 def device_identity(torch, gpu: int) -> str:
     """PCI address of the device this rank decodes on (the same GPU has the same address in every
-    process of the node, whatever index it has there), or its UUID where torch does not tell."""
+    process of the node, whatever index it has there) and its UUID, as far as torch tells them."""
     p = torch.cuda.get_device_properties(gpu)
+    uuid = str(getattr(p, "uuid", "") or "")
     try:
-        return "%04x:%02x:%02x" % (p.pci_domain_id, p.pci_bus_id, p.pci_device_id)
+        pci = "%04x:%02x:%02x" % (p.pci_domain_id, p.pci_bus_id, p.pci_device_id)
     except AttributeError:
-        return str(getattr(p, "uuid", f"index:{gpu}"))
+        return uuid or f"index:{gpu}"
+    # partitions of one card share its PCI address and differ in their UUID: both, where torch tells both
+    return f"{pci}/{uuid}" if uuid else pci
 
 
 def job_report(elapsed_s: float, units: float, step_ms: float, device_id: str, red_dev, one_gpu_per_rank: bool):
