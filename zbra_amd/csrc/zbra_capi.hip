@@ -621,10 +621,11 @@ static int enum_rows_batch_dev(DeviceCtx *ctx, const zbra_enum_desc *descs, size
     // host-filled: variant tags, descriptors, first tile of each array
     const size_t off_desc = align_up(ENUM_MAX_VARIANTS * sizeof(uint32_t), 64);
     const size_t off_ts = align_up(off_desc + nd * sizeof(zbra_enum_desc), 64);
-    const size_t host_bytes = off_ts + (nd + 1) * sizeof(uint64_t);
-    // device only: first unknown-tag row of each array, tile -> array, per-variant tile counts and chunk prefixes
-    const size_t off_bad = align_up(host_bytes, 64);
-    const size_t off_map = align_up(off_bad + nd * sizeof(unsigned long long), 64);
+    // ... and every array's "first row with an unknown tag" word, which starts as "none" (all ones)
+    const size_t off_bad = align_up(off_ts + (nd + 1) * sizeof(uint64_t), 64);
+    const size_t host_bytes = off_bad + nd * sizeof(unsigned long long);
+    // device only: tile -> array, per-variant tile counts and chunk prefixes
+    const size_t off_map = align_up(host_bytes, 64);
     const size_t off_counts = align_up(off_map + (nd > 1 ? (size_t)ntiles * sizeof(uint32_t) : 0), 64);
     const size_t total = off_counts + (size_t)n_variants * (ntiles + nchunks + 1) * sizeof(uint64_t);
     Slot *s;
@@ -636,6 +637,7 @@ static int enum_rows_batch_dev(DeviceCtx *ctx, const zbra_enum_desc *descs, size
     uint64_t run = 0;
     for (size_t i = 0; i < nd; i++) { h_ts[i] = run; run += (descs[i].n + ENUM_TILE - 1) / ENUM_TILE; }
     h_ts[nd] = run;
+    std::memset((char *)s->host + off_bad, 0xFF, nd * sizeof(unsigned long long));
     const uint32_t *d_vt = (const uint32_t *)s->dev;
     unsigned long long *d_bad = (unsigned long long *)((char *)s->dev + off_bad);
     uint64_t *tile_counts = (uint64_t *)((char *)s->dev + off_counts);
@@ -648,7 +650,8 @@ static int enum_rows_batch_dev(DeviceCtx *ctx, const zbra_enum_desc *descs, size
     batch.ntiles = ntiles;
     int st = hip_status(hipMemcpyAsync(s->dev, s->host, host_bytes, hipMemcpyHostToDevice, stream));
     if (st == ZBRA_OK) {
-        hipLaunchKernelGGL(enum_map_kernel, dim3((unsigned)nd), dim3(256), 0, stream, batch, (uint32_t *)((char *)s->dev + off_map), d_bad);
+        if (nd > 1)  // the tile -> array table (a single array needs none; the unknown-tag words came down with the descriptors)
+            hipLaunchKernelGGL(enum_map_kernel, dim3((unsigned)nd), dim3(256), 0, stream, batch, (uint32_t *)((char *)s->dev + off_map));
         if (ntiles) {
             if (n_variants <= (uint32_t)ENUM_FEW) {
                 const uint64_t per_wg = (uint64_t)ENUM_WAVES * ENUM_COUNT_TILES;
@@ -657,21 +660,27 @@ static int enum_rows_batch_dev(DeviceCtx *ctx, const zbra_enum_desc *descs, size
             } else {
                 hipLaunchKernelGGL(enum_counts_kernel, dim3((unsigned)ntiles), dim3(ENUM_THREADS), 0, stream, batch, d_vt, n_variants, tile_counts, d_bad);
             }
-            if (n_variants) {
+            if (n_variants)
                 hipLaunchKernelGGL(enum_scan_chunks_kernel, dim3((unsigned)nchunks, n_variants), dim3(SCAN_CHUNK), 0, stream, ntiles, nchunks,
                                    tile_counts, chunk_base);
-                hipLaunchKernelGGL(enum_scan_totals_kernel, dim3(n_variants), dim3(SCAN_CHUNK), 0, stream, nchunks, chunk_base);
-            }
         }
-        if (n_variants)  // with no tile at all every count is zero, and the kernel reads nothing of the scans
+        // few arrays and few chunks: the totals' scan, the arrays' counts and the status words in one launch of one
+        // workgroup (the unknown-tag words are final after the counting pass: the write pass does not touch them)
+        const bool merged = n_variants && (uint64_t)nd * n_variants <= 65536 && nchunks * n_variants <= 65536;
+        if (merged) {
+            hipLaunchKernelGGL(enum_totals_kernel, dim3(1), dim3(SCAN_CHUNK), 0, stream, batch, n_variants, nchunks, tile_counts, chunk_base, d_bad, d_results);
+        } else if (n_variants) {
+            if (ntiles) hipLaunchKernelGGL(enum_scan_totals_kernel, dim3(n_variants), dim3(SCAN_CHUNK), 0, stream, nchunks, chunk_base);
+            // with no tile at all every count is zero, and the kernel reads nothing of the scans
             hipLaunchKernelGGL(enum_array_counts_kernel, dim3((unsigned)((nd * n_variants + 255) / 256)), dim3(256), 0, stream, batch, n_variants, nchunks,
                                tile_counts, chunk_base);
+        }
         if (ntiles) {
             const int rev = tuning().enum_reverse;
             hipLaunchKernelGGL(enum_write_kernel, dim3((unsigned)ntiles), dim3(ENUM_THREADS), 0, stream, batch, d_vt, n_variants, nchunks, tile_counts,
                                chunk_base, rev < 0 ? (all_rows * 4 > ((uint64_t)208 << 20) ? 1u : 0u) : (uint32_t)rev);
         }
-        hipLaunchKernelGGL(enum_report_kernel, dim3((unsigned)((nd + 255) / 256)), dim3(256), 0, stream, batch, d_bad, d_results);
+        if (!merged) hipLaunchKernelGGL(enum_report_kernel, dim3((unsigned)((nd + 255) / 256)), dim3(256), 0, stream, batch, d_bad, d_results);
         st = hip_status(hipGetLastError());
     }
     int st2 = ctx->release(s, stream);

@@ -354,13 +354,53 @@ __global__ void enum_report_kernel(EnumBatch batch, const unsigned long long *fi
     results[a] = res;
 }
 
-// tile -> array table of a submission and the arrays' "no unknown tag seen" words.  One workgroup per array.
-__global__ __launch_bounds__(256) void enum_map_kernel(EnumBatch batch, uint32_t *__restrict__ tile_map, unsigned long long *first_bad_row) {
+// The three small steps between the counting and the writing pass as ONE launch, for submissions of
+// few arrays: the scan of the chunk totals of every variant, every array's counts, the status words.
+// One workgroup: the steps depend on each other only through what this workgroup itself wrote
+// (a barrier orders that), and each of the three launches it replaces cost a kernel boundary.
+__global__ __launch_bounds__(SCAN_CHUNK) void enum_totals_kernel(EnumBatch batch, uint32_t nv, uint64_t nchunks, const uint64_t *__restrict__ tile_counts,
+                                                                 uint64_t *__restrict__ chunk_base, const unsigned long long *first_bad_row,
+                                                                 zbra_dev_result *results) {
+    __shared__ uint64_t wtot[SCAN_CHUNK / 64];
+    if (batch.ntiles) {
+        for (uint32_t v = 0; v < nv; v++) {  // as enum_scan_totals_kernel, variant after variant
+            uint64_t *col = chunk_base + (uint64_t)v * (nchunks + 1);
+            uint64_t carry = 0;
+            for (uint64_t c0 = 0; c0 < nchunks; c0 += SCAN_CHUNK) {  // uniform trip count
+                const uint64_t c = c0 + threadIdx.x;
+                const uint64_t x = c < nchunks ? col[c] : 0;
+                uint64_t total;
+                const uint64_t ex = block_exclusive_scan_1024(x, wtot, &total);
+                if (c < nchunks) col[c] = carry + ex;
+                carry += total;
+            }
+            if (threadIdx.x == 0) col[nchunks] = carry;
+        }
+    }
+    __syncthreads();  // the scanned columns, written by this workgroup, are read below
+    for (uint64_t i = threadIdx.x; i < (uint64_t)batch.nd * nv; i += SCAN_CHUNK) {  // as enum_array_counts_kernel
+        const uint32_t a = (uint32_t)(i / nv), v = (uint32_t)(i % nv);
+        const uint64_t S = batch.tile_start[a], E = batch.tile_start[a + 1];
+        batch.arrays[a].counts[v] = E == S ? 0 : enum_prefix(tile_counts, chunk_base, batch.ntiles, nchunks, v, E) -
+                                                 enum_prefix(tile_counts, chunk_base, batch.ntiles, nchunks, v, S);
+    }
+    if (results) {
+        for (uint32_t a = threadIdx.x; a < batch.nd; a += SCAN_CHUNK) {  // as enum_report_kernel
+            const zbra_enum_desc d = batch.arrays[a];
+            zbra_dev_result res;
+            res.status = ZBRA_OK; res.width = 0; res.out_count = d.n; res.midpoint = 0; res.packed_len = 0;
+            const unsigned long long bad = first_bad_row[a];
+            if (bad != ~0ull) { res.status = ZBRA_ERR_UNKNOWN_TAG; res.out_count = bad; res.midpoint = (int64_t)d.tags[bad]; }
+            results[a] = res;
+        }
+    }
+}
+
+// tile -> array table of a submission of several arrays.  One workgroup per array.
+__global__ __launch_bounds__(256) void enum_map_kernel(EnumBatch batch, uint32_t *__restrict__ tile_map) {
     const uint32_t a = blockIdx.x;
     if (a >= batch.nd) return;
-    if (threadIdx.x == 0) first_bad_row[a] = ~0ull;
-    if (batch.nd > 1)
-        for (uint64_t t = batch.tile_start[a] + threadIdx.x; t < batch.tile_start[a + 1]; t += blockDim.x) tile_map[t] = a;
+    for (uint64_t t = batch.tile_start[a] + threadIdx.x; t < batch.tile_start[a + 1]; t += blockDim.x) tile_map[t] = a;
 }
 
 }  // namespace zbra
