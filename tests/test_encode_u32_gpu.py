@@ -188,6 +188,17 @@ def test_framed_equal_length_tag_arrays(env):
     assert all(r.status == 0 for r in device.read_results(res))
     got = out.cpu().numpy()
     assert int(offs[na]) == len(want) and got[:len(want)].tobytes() == want and (got[len(want):] == 0xEE).all()
+    # a buffer that ends inside frame 7: frames 0..6 as before, 7 and later reported and not written
+    ends = np.cumsum([8 + len(oc.compress_int_array(c.astype(np.int64))) for c in cols])
+    cap = int(ends[6]) + 5
+    out.fill_(0xEE)
+    device.encode_frames_dev(device.make_encode_descs([(d.data_ptr(), n, 0, 0, L.ELEM_U32) for d in d_cols]), out[:cap], offs, res)
+    torch.cuda.synchronize()
+    rs = device.read_results(res)
+    assert [r.status for r in rs] == [0] * 7 + [L.ERR_CAPACITY] * (na - 7)
+    got = out.cpu().numpy()
+    assert got[:ends[6]].tobytes() == want[:ends[6]] and (got[ends[6]:] == 0xEE).all()
+    assert [int(o) for o in offs.cpu()] == [0] + [int(e) for e in ends[:7]] + [int(ends[6])] * (na - 7)
 
 
 def test_ragged_and_mixed_batches_keep_the_generic_kernel(env):
